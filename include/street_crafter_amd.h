@@ -1,0 +1,161 @@
+/*
+ * street_crafter_amd -- C ABI of the MI355X (gfx950) Gaussian-splat hot path.
+ *
+ * This is the drop-in boundary: plain pointers + sizes, no torch types.  Every pointer is a
+ * DEVICE pointer unless its name ends in _host.  `stream` is a hipStream_t passed as void*.
+ * Every entry point returns 0 on success, a hipError_t (>0) from the runtime, or a negative
+ * SC_E* code for an argument the library rejects before launching anything.
+ *
+ * What each entry point replaces (reference = zzz5y/street_crafter, paths under /root/reference):
+ *   sc_projection_fwd/bwd   gsplat.rendering.fully_fused_projection
+ *                           called at street_gaussian/models/street_gaussian_renderer.py:219-232
+ *   sc_isect_*              gsplat.rendering.isect_tiles           renderer.py:243-252
+ *   sc_isect_offsets        gsplat.rendering.isect_offset_encode   renderer.py:253
+ *   sc_sh_fwd/bwd           gsplat.rendering.spherical_harmonics   renderer.py:259
+ *   sc_rasterize_fwd/bwd    gsplat.rendering.rasterize_to_pixels   renderer.py:267-280
+ *                           (backward reached from train.py:236; absgrad read at
+ *                            street_gaussian/models/street_gaussian_model.py:505-506)
+ *   sc_knn3_mean_dist2      simple_knn._C.distCUDA2
+ *                           street_gaussian/models/gaussian_model.py:65,
+ *                           gaussian_model_actor.py:139, data_processor/utils/render_utils.py:125
+ * The CUDA sources of gsplat / simple-knn are not vendored in the reference;
+ * semantics follow SURVEY.md Appendix A and are pinned by oracle/ + tests/golden/.
+ *
+ * Layouts: all float tensors fp32, row-major, innermost dimension contiguous:
+ *   means[N,3] quats[N,4](wxyz) scales[N,3] viewmats[C,4,4](world->cam) Ks[C,3,3]
+ *   radii i32[C,N]  means2d[C,N,2]  depths[C,N]  conics[C,N,3]  compensations[C,N]
+ *   isect_ids i64[I] = (cam << (32+tile_bits)) | (tile << 32) | depth_bits ; flatten_ids i32[I] = cam*N+n
+ *   isect_offsets i32[C,tile_h,tile_w] ; colors[C,N,D] ; opacities[C,N]
+ *   render_colors[C,H,W,D] render_alphas[C,H,W,1] last_ids i32[C,H,W]
+ */
+#ifndef STREET_CRAFTER_AMD_H
+#define STREET_CRAFTER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sc_stream_t;
+
+#define SC_OK 0
+#define SC_EINVAL (-1)      /* bad size / null pointer / unsupported parameter */
+#define SC_EWORKSPACE (-2)  /* workspace too small */
+#define SC_EUNSUPPORTED (-3)
+
+/* ---- library info ------------------------------------------------------------------- */
+const char* sc_version(void);
+const char* sc_error_string(int code);
+/* compiled-for architecture string, e.g. "gfx950" */
+const char* sc_target_arch(void);
+
+/* ---- a1: projection (renderer.py:219-232) -------------------------------------------- */
+int sc_projection_fwd(const float* means, const float* quats, const float* scales,
+                      const float* viewmats, const float* Ks, int C, int N, int width, int height,
+                      float eps2d, float near_plane, float far_plane, float radius_clip,
+                      int32_t* radii, float* means2d, float* depths, float* conics,
+                      float* compensations /* nullable */, sc_stream_t stream);
+
+/* VJP of sc_projection_fwd w.r.t. means/quats/scales (camera tensors carry no grad at the
+ * reference's call site).  v_compensations nullable.  Outputs are OVERWRITTEN (summed over C). */
+int sc_projection_bwd(const float* means, const float* quats, const float* scales,
+                      const float* viewmats, const float* Ks, int C, int N, int width, int height,
+                      float eps2d, const int32_t* radii, const float* conics,
+                      const float* compensations /* nullable */,
+                      const float* v_means2d, const float* v_depths, const float* v_conics,
+                      const float* v_compensations /* nullable */,
+                      float* v_means, float* v_quats, float* v_scales, sc_stream_t stream);
+
+/* ---- a3: tile intersection (renderer.py:243-252) -------------------------------------- */
+/* workspace bytes needed by sc_isect_count/sc_isect_emit for CN = C*N gaussians */
+size_t sc_isect_workspace_bytes(int64_t CN);
+/* pass 1: tiles_per_gauss[C,N] and the total number of intersections (device int64). */
+int sc_isect_count(const float* means2d, const int32_t* radii, int C, int N,
+                   int tile_size, int tile_width, int tile_height,
+                   int32_t* tiles_per_gauss, int64_t* total_dev, void* workspace, size_t ws_bytes,
+                   sc_stream_t stream);
+/* pass 2: unsorted keys/values in emission order (gaussian-major, row-major over the rect).
+ * Must be called with the workspace left by sc_isect_count. */
+int sc_isect_emit(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
+                  int tile_size, int tile_width, int tile_height,
+                  const int32_t* tiles_per_gauss, int64_t n_isects,
+                  int64_t* isect_ids, int32_t* flatten_ids, void* workspace, size_t ws_bytes,
+                  sc_stream_t stream);
+
+/* stable LSD radix sort of (u64 key, i32 value) pairs over key bits [0, end_bit). In place:
+ * on return keys/vals hold the sorted result.  tmp_* are scratch of the same size. */
+size_t sc_radix_sort_workspace_bytes(int64_t n);
+int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_keys, int32_t* tmp_vals,
+                                int64_t n, int end_bit, void* workspace, size_t ws_bytes,
+                                sc_stream_t stream);
+
+/* Fused tile-bucketed path: produces exactly what count + emit + stable sort + offset-encode
+ * produce (bit-identical isect_ids / flatten_ids / offsets) with one bucket pass and one
+ * in-LDS sort per tile.  Two calls because the caller must size the outputs in between:
+ *   sc_isect_bin_count : tiles_per_gauss, per-tile offsets (= isect_offset_encode result) and total
+ *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted
+ */
+size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_isects);
+int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
+                       int tile_size, int tile_width, int tile_height,
+                       int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* total_dev,
+                       void* workspace, size_t ws_bytes, sc_stream_t stream);
+int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
+                      int tile_size, int tile_width, int tile_height,
+                      const int32_t* isect_offsets, int64_t n_isects,
+                      int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
+                      void* workspace, size_t ws_bytes, sc_stream_t stream);
+
+/* ---- a4: offsets (renderer.py:253) ---------------------------------------------------- */
+int sc_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int C, int tile_width,
+                     int tile_height, int32_t* offsets, sc_stream_t stream);
+
+/* ---- a6: spherical harmonics (renderer.py:259) ---------------------------------------- */
+/* M rows; dirs[M,3], coeffs[M,K,3] (K >= (degree+1)^2 coefficients per row, row stride K),
+ * masks uint8[M] nullable; colors[M,3].  Masked-out rows are written as 0. */
+int sc_sh_fwd(int degree, const float* dirs, const float* coeffs, const uint8_t* masks,
+              int64_t M, int K, float* colors, sc_stream_t stream);
+/* v_dirs nullable. v_coeffs[M,K,3] fully written (zeros beyond the used bases / masked rows). */
+int sc_sh_bwd(int degree, const float* dirs, const float* coeffs, const uint8_t* masks,
+              int64_t M, int K, const float* v_colors, float* v_coeffs, float* v_dirs,
+              sc_stream_t stream);
+
+/* ---- a9: rasterize (renderer.py:267-280) ---------------------------------------------- */
+/* D = number of colour channels, 1..32 (3 and 4 have dedicated kernels).
+ * backgrounds[C,D] nullable; tile_masks uint8[C,tile_h,tile_w] nullable (0 = skip tile). */
+int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
+                     const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
+                     int C, int N, int D, int width, int height, int tile_size,
+                     int tile_width, int tile_height,
+                     const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
+                     float* render_colors, float* render_alphas, int32_t* last_ids,
+                     sc_stream_t stream);
+/* Gradient outputs must be ZERO-FILLED by the caller (the kernel accumulates with atomics).
+ * v_means2d_abs nullable (absgrad). */
+int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
+                     const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
+                     int C, int N, int D, int width, int height, int tile_size,
+                     int tile_width, int tile_height,
+                     const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
+                     const float* render_alphas, const int32_t* last_ids,
+                     const float* v_render_colors, const float* v_render_alphas,
+                     float* v_means2d_abs, float* v_means2d, float* v_conics, float* v_colors,
+                     float* v_opacities, sc_stream_t stream);
+
+/* ---- a14: simple_knn.distCUDA2 --------------------------------------------------------- */
+size_t sc_knn_workspace_bytes(int64_t n);
+int sc_knn3_mean_dist2(const float* points, int64_t n, float* out, void* workspace,
+                       size_t ws_bytes, sc_stream_t stream);
+
+/* ---- tuning / introspection ------------------------------------------------------------ */
+/* Select a kernel variant at run time (for A/B measurements in one process).
+ *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled (default)
+ * Returns the previous value, or SC_EINVAL for an unknown key. */
+int sc_set_option(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREET_CRAFTER_AMD_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI declared in include/street_crafter_amd.h.
+
+The HIP shared library is the product: there is NO CPU / torch fallback.  If the library is
+missing, importing an operator raises ImportError naming the build command; if a tensor is not
+on a HIP device the operator raises before launching anything.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstreet_crafter_hip.so")
+
+_lib = None
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+c_u64p = C.c_void_p
+c_stream = C.c_void_p
+
+# name -> (restype, argtypes); must match include/street_crafter_amd.h exactly
+SIGNATURES = {
+    "sc_version": (C.c_char_p, []),
+    "sc_error_string": (C.c_char_p, [C.c_int]),
+    "sc_target_arch": (C.c_char_p, []),
+    "sc_projection_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, c_i32p, c_f32p,
+                                    c_f32p, c_f32p, c_f32p, c_stream]),
+    "sc_projection_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                    c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "sc_isect_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "sc_isect_count": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+                                 c_i64p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_isect_emit": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                c_i32p, C.c_int64, c_i64p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_radix_sort_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "sc_radix_sort_pairs_u64_i32": (C.c_int, [c_u64p, c_i32p, c_u64p, c_i32p, C.c_int64, C.c_int,
+                                              C.c_void_p, C.c_size_t, c_stream]),
+    "sc_isect_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "sc_isect_bin_count": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+                                     c_i32p, c_i64p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    c_i32p, C.c_int64, c_i64p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_isect_offsets": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, c_i32p, c_stream]),
+    "sc_sh_fwd": (C.c_int, [C.c_int, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int, c_f32p, c_stream]),
+    "sc_sh_bwd": (C.c_int, [C.c_int, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int, c_f32p, c_f32p, c_f32p,
+                            c_stream]),
+    "sc_rasterize_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
+                                   c_f32p, c_f32p, c_i32p, c_stream]),
+    "sc_rasterize_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
+                                   c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                   c_stream]),
+    "sc_knn_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "sc_knn3_mean_dist2": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+}
+
+
+def load():
+    """Returns the ctypes handle, loading it on first use; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"street_crafter_amd: HIP library not built ({LIB_PATH} missing). "
+            "Build it with `python -m street_crafter_amd.build` (needs hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().sc_error_string(int(code)).decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def set_option(key: str, value: int) -> int:
+    prev = load().sc_set_option(key.encode(), int(value))
+    if prev < 0:
+        raise ValueError(f"unknown option {key}={value}")
+    return prev

@@ -1,0 +1,195 @@
+// a11: rasterize_to_pixels backward for gfx950.
+// Reached from the reference through loss.backward() (train.py:236); the absgrad output is what
+// street_gaussian/models/street_gaussian_model.py:505-506 reads as `means2d.absgrad`.
+//
+// One workgroup per tile, one lane per pixel; the tile's splat list is replayed back to front
+// from the last splat any pixel of the wave blended.  Per splat the 64 lanes' contributions are
+// summed across the wave first, then one lane issues the global float atomics (gradient
+// buffers must arrive zero-filled).  Float atomics make the result order-dependent in the last
+// bits; tests compare against the autograd oracle with a tolerance.
+#include "raster_common.h"
+
+namespace {
+
+template <int CDIM>
+__global__ void raster_bwd_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N, int D,
+    int width, int height, int tile_size, int tile_width, int tile_height,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
+    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    constexpr int ND = CDIM > 0 ? CDIM : SC_MAX_CDIM;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int B = blockDim.x * blockDim.y;
+    int* id_s = reinterpret_cast<int*>(smem);                              // [B]
+    float4* xyoa_s = reinterpret_cast<float4*>(smem + (size_t)B * 16);     // [B]
+    float2* bc_s = reinterpret_cast<float2*>(smem + (size_t)B * 32);       // [B]
+    float* rgb_s = reinterpret_cast<float*>(smem + (size_t)B * 40);        // [B * D]
+
+    const int cam = blockIdx.z;
+    const int tile_id = blockIdx.y * tile_width + blockIdx.x;
+    const int tflat = cam * tile_width * tile_height + tile_id;
+    if (tile_masks && !tile_masks[tflat]) return;
+    const int px_i = blockIdx.x * tile_size + threadIdx.x;
+    const int py_i = blockIdx.y * tile_size + threadIdx.y;
+    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const bool inside = (px_i < width) && (py_i < height);
+    const int64_t pix = inside ? ((int64_t)cam * height + py_i) * width + px_i : 0;
+    const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+    const int lane = tr & 63;
+
+    const int range_start = isect_offsets[tflat];
+    const int total_tiles = gridDim.z * tile_width * tile_height;
+    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    const int num_batches = (range_end - range_start + B - 1) / B;
+
+    const float T_final = inside ? 1.0f - render_alphas[pix] : 1.0f;
+    float T = T_final;
+    float buffer[ND];
+    float v_rc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        buffer[d] = 0.f;
+        v_rc[d] = (inside && (CDIM > 0 || d < D)) ? v_render_colors[pix * D + d] : 0.f;
+    }
+    const float v_ra = inside ? v_render_alphas[pix] : 0.f;
+    float bg_dot = 0.f;
+    if (backgrounds) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            if (CDIM > 0 || d < D) bg_dot += backgrounds[cam * D + d] * v_rc[d];
+    }
+    const int bin_final = inside ? last_ids[pix] : 0;
+    int wave_bin_final = bin_final;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wave_bin_final = max(wave_bin_final, __shfl_xor(wave_bin_final, o, 64));
+
+    for (int b = 0; b < num_batches; ++b) {
+        __syncthreads();
+        const int batch_end = range_end - 1 - B * b;
+        const int bsz = min(B, batch_end + 1 - range_start);
+        const int idx = batch_end - tr;
+        if (idx >= range_start) {
+            const int g = flatten_ids[idx];
+            id_s[tr] = g;
+            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+            const float* cn = conics + (int64_t)g * 3;
+            xyoa_s[tr] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
+            bc_s[tr] = make_float2(cn[1], cn[2]);
+            for (int d = 0; d < D; ++d) rgb_s[tr * D + d] = colors[(int64_t)g * D + d];
+        }
+        __syncthreads();
+        for (int t = max(0, batch_end - wave_bin_final); t < bsz; ++t) {
+            bool valid = inside && (batch_end - t <= bin_final);
+            float alpha = 0.f, opac = 0.f, vis = 0.f, dx = 0.f, dy = 0.f;
+            float ca = 0.f, cb = 0.f, cc = 0.f;
+            if (valid) {
+                const float4 a = xyoa_s[t];
+                const float2 bc = bc_s[t];
+                ca = a.w; cb = bc.x; cc = bc.y; opac = a.z;
+                dx = a.x - px; dy = a.y - py;
+                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+                vis = sc_fast_exp(-sigma);
+                alpha = fminf(SC_ALPHA_MAX, opac * vis);
+                if (sigma < 0.f || alpha < SC_ALPHA_MIN) valid = false;
+            }
+            if (!__any(valid)) continue;
+            float v_rgb[ND];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) v_rgb[d] = 0.f;
+            float v_con0 = 0.f, v_con1 = 0.f, v_con2 = 0.f, v_x = 0.f, v_y = 0.f, v_xa = 0.f, v_ya = 0.f, v_op = 0.f;
+            if (valid) {
+                const float ra = 1.0f / (1.0f - alpha);
+                T *= ra;
+                const float fac = alpha * T;
+                float v_alpha = 0.f;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    if (CDIM > 0 || d < D) {
+                        const float c = rgb_s[t * D + d];
+                        v_rgb[d] = fac * v_rc[d];
+                        v_alpha += (c * T - buffer[d] * ra) * v_rc[d];
+                        buffer[d] += c * fac;
+                    }
+                }
+                v_alpha += T_final * ra * v_ra;
+                if (backgrounds) v_alpha += -T_final * ra * bg_dot;
+                if (opac * vis <= SC_ALPHA_MAX) {
+                    const float v_sigma = -opac * vis * v_alpha;
+                    v_con0 = 0.5f * v_sigma * dx * dx;
+                    v_con1 = v_sigma * dx * dy;
+                    v_con2 = 0.5f * v_sigma * dy * dy;
+                    v_x = v_sigma * (ca * dx + cb * dy);
+                    v_y = v_sigma * (cb * dx + cc * dy);
+                    v_xa = fabsf(v_x);
+                    v_ya = fabsf(v_y);
+                    v_op = vis * v_alpha;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if (CDIM > 0 || d < D) v_rgb[d] = sc_wave_sum(v_rgb[d]);
+            v_con0 = sc_wave_sum(v_con0); v_con1 = sc_wave_sum(v_con1); v_con2 = sc_wave_sum(v_con2);
+            v_x = sc_wave_sum(v_x); v_y = sc_wave_sum(v_y); v_op = sc_wave_sum(v_op);
+            if (v_means2d_abs) { v_xa = sc_wave_sum(v_xa); v_ya = sc_wave_sum(v_ya); }
+            if (lane == 0) {
+                const int64_t g = id_s[t];
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if (CDIM > 0 || d < D) atomicAdd(v_colors + g * D + d, v_rgb[d]);
+                atomicAdd(v_conics + g * 3 + 0, v_con0);
+                atomicAdd(v_conics + g * 3 + 1, v_con1);
+                atomicAdd(v_conics + g * 3 + 2, v_con2);
+                atomicAdd(v_means2d + g * 2 + 0, v_x);
+                atomicAdd(v_means2d + g * 2 + 1, v_y);
+                if (v_means2d_abs) {
+                    atomicAdd(v_means2d_abs + g * 2 + 0, v_xa);
+                    atomicAdd(v_means2d_abs + g * 2 + 1, v_ya);
+                }
+                atomicAdd(v_opacities + g, v_op);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
+                                const float* opacities, const float* backgrounds,
+                                const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                                int tile_size, int tile_width, int tile_height,
+                                const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                int64_t n_isects, const float* render_alphas, const int32_t* last_ids,
+                                const float* v_render_colors, const float* v_render_alphas,
+                                float* v_means2d_abs, float* v_means2d, float* v_conics,
+                                float* v_colors, float* v_opacities, sc_stream_t stream) {
+    if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
+    if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
+    if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
+    if ((int64_t)tile_width * tile_size < width || (int64_t)tile_height * tile_size < height) return SC_EINVAL;
+    if (C == 0 || n_isects == 0) return SC_OK;
+    if (!means2d || !conics || !colors || !opacities || !isect_offsets || !flatten_ids || !render_alphas ||
+        !last_ids || !v_render_colors || !v_render_alphas || !v_means2d || !v_conics || !v_colors ||
+        !v_opacities)
+        return SC_EINVAL;
+    if (C > 65535 || tile_height > 65535) return SC_EINVAL;
+    dim3 grid(tile_width, tile_height, C), block(tile_size, tile_size);
+    const size_t B = (size_t)tile_size * tile_size;
+    const size_t shmem = B * 40 + B * D * 4;
+#define SC_LAUNCH_BWD(CD)                                                                              \
+    hipLaunchKernelGGL(raster_bwd_kernel<CD>, grid, block, shmem, sc_s(stream), means2d, conics, colors,   \
+                       opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,     \
+                       tile_height, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,    \
+                       v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors,     \
+                       v_opacities)
+    if (D == 4) SC_LAUNCH_BWD(4);
+    else if (D == 3) SC_LAUNCH_BWD(3);
+    else SC_LAUNCH_BWD(0);
+#undef SC_LAUNCH_BWD
+    SC_LAUNCH_CHECK();
+    return SC_OK;
+}

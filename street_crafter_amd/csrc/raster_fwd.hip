@@ -1,0 +1,342 @@
+// a9: rasterize_to_pixels forward for gfx950.
+// Replaces gsplat.rendering.rasterize_to_pixels as called at
+// street_gaussian/models/street_gaussian_renderer.py:267-280 (semantics: SURVEY.md A.5).
+//
+// Two variants, selectable at run time with sc_set_option("raster_fwd", v) for A/B runs:
+//   0  reference-shaped: one lane per pixel, every lane evaluates every splat of the tile.
+//   1  culled (default, tile_size 16): while a batch is staged into LDS each staging lane tests
+//      its splat's alpha >= 1/255 ellipse against the tile rectangle (an exact, conservative
+//      test) and the batch is compacted with a wave ballot + prefix sum, so the per-pixel loop
+//      only walks splats that can touch the tile.  Splats that are dropped would have been
+//      skipped by every pixel (alpha < 1/255 leaves T, the colour sums and last_ids untouched),
+//      so the output is identical to variant 0.
+// The blend itself uses v_exp_f32 (fast exp) and FMA contraction: pixels agree with the oracle
+// to ~1e-6 relative, not bitwise (tolerance stated in tests/test_gpu_parity.py).
+#include "raster_common.h"
+
+int g_sc_raster_fwd_variant = 1;
+
+namespace {
+
+constexpr int MAXB = 1024;  // max lanes per tile workgroup (tile_size <= 32)
+
+// ------------------------------------------------------------------------------------------
+// variant 0: reference-shaped
+// ------------------------------------------------------------------------------------------
+template <int CDIM>
+__global__ void raster_fwd_ref_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N, int D,
+    int width, int height, int tile_size, int tile_width, int tile_height,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas,
+    int32_t* __restrict__ last_ids) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int B = blockDim.x * blockDim.y;
+    int* id_s = reinterpret_cast<int*>(smem);                              // [B]
+    float4* xyoa_s = reinterpret_cast<float4*>(smem + (size_t)B * 16);     // [B] mx,my,opac,conic.a
+    float2* bc_s = reinterpret_cast<float2*>(smem + (size_t)B * 32);       // [B] conic.b, conic.c
+    __shared__ int done_cnt_s;
+
+    const int cam = blockIdx.z;
+    const int tile_id = blockIdx.y * tile_width + blockIdx.x;
+    const int tflat = cam * tile_width * tile_height + tile_id;
+    const int px_i = blockIdx.x * tile_size + threadIdx.x;
+    const int py_i = blockIdx.y * tile_size + threadIdx.y;
+    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const bool inside = (px_i < width) && (py_i < height);
+    const int64_t pix = ((int64_t)cam * height + py_i) * width + px_i;
+    const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+
+    if (tile_masks && !tile_masks[tflat]) {
+        if (inside) {
+            for (int d = 0; d < D; ++d)
+                render_colors[pix * D + d] = backgrounds ? backgrounds[cam * D + d] : 0.f;
+            render_alphas[pix] = 0.f;
+            last_ids[pix] = 0;
+        }
+        return;
+    }
+
+    const int range_start = isect_offsets[tflat];
+    const int total_tiles = gridDim.z * tile_width * tile_height;
+    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    const int num_batches = (range_end - range_start + B - 1) / B;
+
+    float T = 1.0f;
+    int cur_idx = 0;
+    bool done = !inside;
+    float pix_out[CDIM > 0 ? CDIM : SC_MAX_CDIM];
+    constexpr int ND = CDIM > 0 ? CDIM : SC_MAX_CDIM;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) pix_out[d] = 0.f;
+
+    for (int b = 0; b < num_batches; ++b) {
+        if (__syncthreads_count(done) >= B) break;
+        const int batch_start = range_start + B * b;
+        const int idx = batch_start + tr;
+        if (idx < range_end) {
+            const int g = flatten_ids[idx];
+            id_s[tr] = g;
+            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+            const float* cn = conics + (int64_t)g * 3;
+            xyoa_s[tr] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
+            bc_s[tr] = make_float2(cn[1], cn[2]);
+        }
+        __syncthreads();
+        const int bsz = min(B, range_end - batch_start);
+        for (int t = 0; (t < bsz) && !done; ++t) {
+            const float4 a = xyoa_s[t];
+            const float2 bc = bc_s[t];
+            const float dx = a.x - px, dy = a.y - py;
+            const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
+            const float alpha = fminf(SC_ALPHA_MAX, a.z * sc_fast_exp(-sigma));
+            if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
+            const float next_T = T * (1.0f - alpha);
+            if (next_T <= SC_T_EPS) { done = true; break; }
+            const float vis = alpha * T;
+            const float* c = colors + (int64_t)id_s[t] * D;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+                if (CDIM > 0 || d < D) pix_out[d] += c[d] * vis;
+            cur_idx = batch_start + t;
+            T = next_T;
+        }
+    }
+    (void)done_cnt_s;
+    if (inside) {
+        render_alphas[pix] = 1.0f - T;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            if (CDIM > 0 || d < D)
+                render_colors[pix * D + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * D + d] : pix_out[d];
+        last_ids[pix] = cur_idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// variant 1: culled, tile 16x16, 256 lanes = 4 waves, CDIM in {3,4}
+// ------------------------------------------------------------------------------------------
+// Minimum of q(x,y) = 0.5*(A x^2 + C y^2) + B x y  over the rectangle [x0,x1] x [y0,y1]
+// (coordinates relative to the splat centre).  q is a convex quadratic when the conic is
+// positive definite; returns 0 if the centre is inside.
+__device__ __forceinline__ float min_quad_on_rect(float A, float Bc, float Cc, float x0, float x1,
+                                                  float y0, float y1) {
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
+    float best = 3.0e38f;
+    // vertical edges x = xe: minimise over y -> y* = -B xe / C clamped
+    const float invC = 1.0f / Cc, invA = 1.0f / A;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float xe = e ? x1 : x0;
+        float ys = fminf(fmaxf(-Bc * xe * invC, y0), y1);
+        best = fminf(best, 0.5f * (A * xe * xe + Cc * ys * ys) + Bc * xe * ys);
+        const float ye = e ? y1 : y0;
+        float xs = fminf(fmaxf(-Bc * ye * invA, x0), x1);
+        best = fminf(best, 0.5f * (A * xs * xs + Cc * ye * ye) + Bc * xs * ye);
+    }
+    return best;
+}
+
+// True only when NO pixel centre inside the rectangle can pass the blend loop's test
+// (sigma >= 0 and op*exp(-sigma) >= 1/255, i.e. sigma <= ln(255 op)).  Conservative: the
+// threshold is widened by an absolute margin plus a bound on the fp32 rounding error of both
+// evaluations of the quadratic (2e-6 * the largest magnitude its terms reach on the rectangle);
+// NaN inputs and non positive-definite conics are never dropped (every comparison is false).
+__device__ __forceinline__ bool splat_misses_rect(float A, float Bc, float Cc, float op, float x0,
+                                                  float x1, float y0, float y1) {
+    const float L = __logf(255.0f * op);
+    if (L + 1e-3f + 1e-3f * fabsf(L) < 0.f) return true;   // op*255 < 1: alpha < 1/255 everywhere
+    const bool pd = (A > 0.f) && (Cc > 0.f) && (A * Cc - Bc * Bc > 0.f);
+    if (!pd) return false;
+    const float mx = fmaxf(fabsf(x0), fabsf(x1)), my = fmaxf(fabsf(y0), fabsf(y1));
+    const float S = A * mx * mx + Cc * my * my + 2.0f * fabsf(Bc) * mx * my;
+    const float tau = L + 1e-3f + 1e-3f * fabsf(L) + 2e-6f * S;
+    return min_quad_on_rect(A, Bc, Cc, x0, x1, y0, y1) > tau;
+}
+
+template <int CDIM>
+__global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
+    int width, int height, int tile_width, int tile_height,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas,
+    int32_t* __restrict__ last_ids) {
+    constexpr int B = 256;
+    __shared__ float4 xyoa_s[B];      // mx, my, opac, conic.a
+    __shared__ float4 bck_s[B];       // conic.b, conic.c, k (sorted index, as int bits), -
+    __shared__ float4 col_s[B];       // colour channels
+    __shared__ int wave_cnt_s[4];
+
+    const int cam = blockIdx.z;
+    const int tile_id = blockIdx.y * tile_width + blockIdx.x;
+    const int tflat = cam * tile_width * tile_height + tile_id;
+    const int tr = threadIdx.x;
+    const int lane = tr & 63, wave = tr >> 6;
+    // lane -> pixel: wave w covers rows 4w..4w+3, 16 pixels per row
+    const int lx = tr & 15, ly = tr >> 4;
+    const int px_i = blockIdx.x * 16 + lx, py_i = blockIdx.y * 16 + ly;
+    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const bool inside = (px_i < width) && (py_i < height);
+    const int64_t pix = ((int64_t)cam * height + py_i) * width + px_i;
+
+    if (tile_masks && !tile_masks[tflat]) {
+        if (inside) {
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d)
+                render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
+            render_alphas[pix] = 0.f;
+            last_ids[pix] = 0;
+        }
+        return;
+    }
+    const int range_start = isect_offsets[tflat];
+    const int total_tiles = gridDim.z * tile_width * tile_height;
+    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    const int num_batches = (range_end - range_start + B - 1) / B;
+
+    // tile rectangle in pixel-centre coordinates (only pixels inside the image count)
+    const float rx0 = (float)(blockIdx.x * 16) + 0.5f;
+    const float ry0 = (float)(blockIdx.y * 16) + 0.5f;
+    const float rx1 = (float)min(blockIdx.x * 16 + 15, width - 1) + 0.5f;
+    const float ry1 = (float)min(blockIdx.y * 16 + 15, height - 1) + 0.5f;
+
+    float T = 1.0f;
+    int cur_idx = 0;
+    bool done = !inside;
+    float pix_out[CDIM];
+#pragma unroll
+    for (int d = 0; d < CDIM; ++d) pix_out[d] = 0.f;
+
+    for (int b = 0; b < num_batches; ++b) {
+        if (__syncthreads_count(done) >= B) break;
+        const int batch_start = range_start + B * b;
+        const int idx = batch_start + tr;
+        // ---- stage + cull -------------------------------------------------------------------
+        bool keep = false;
+        float4 v0, v1, v2;
+        if (idx < range_end) {
+            const int g = flatten_ids[idx];
+            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+            const float* cn = conics + (int64_t)g * 3;
+            const float ca = cn[0], cb = cn[1], cc = cn[2];
+            const float op = opacities[g];
+            keep = !splat_misses_rect(ca, cb, cc, op, rx0 - xy.x, rx1 - xy.x, ry0 - xy.y, ry1 - xy.y);
+            v0 = make_float4(xy.x, xy.y, op, ca);
+            v1 = make_float4(cb, cc, __int_as_float(idx), 0.f);
+            if (keep) {
+                const float* c = colors + (int64_t)g * CDIM;
+                v2 = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt_s[wave] = __popcll(m);
+        __syncthreads();   // also orders the previous batch's LDS reads before this batch's writes
+        int base = 0, bsz = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = wave_cnt_s[w];
+            if (w < wave) base += c;
+            bsz += c;
+        }
+        if (keep) {
+            const int slot = base + __popcll(m & sc_lanemask_lt());
+            xyoa_s[slot] = v0;
+            bck_s[slot] = v1;
+            col_s[slot] = v2;
+        }
+        __syncthreads();
+        // ---- blend ---------------------------------------------------------------------------
+        for (int t = 0; (t < bsz) && !done; ++t) {
+            const float4 a = xyoa_s[t];
+            const float4 bc = bck_s[t];
+            const float dx = a.x - px, dy = a.y - py;
+            const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
+            const float alpha = fminf(SC_ALPHA_MAX, a.z * sc_fast_exp(-sigma));
+            if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
+            const float next_T = T * (1.0f - alpha);
+            if (next_T <= SC_T_EPS) { done = true; break; }
+            const float vis = alpha * T;
+            const float4 c = col_s[t];
+            pix_out[0] += c.x * vis;
+            pix_out[1] += c.y * vis;
+            pix_out[2] += c.z * vis;
+            if (CDIM > 3) pix_out[3] += c.w * vis;
+            cur_idx = __float_as_int(bc.z);
+            T = next_T;
+        }
+    }
+    if (inside) {
+        render_alphas[pix] = 1.0f - T;
+        if (CDIM == 4) {
+            float4 o = make_float4(pix_out[0], pix_out[1], pix_out[2], pix_out[3]);
+            if (backgrounds) {
+                o.x += T * backgrounds[cam * 4 + 0]; o.y += T * backgrounds[cam * 4 + 1];
+                o.z += T * backgrounds[cam * 4 + 2]; o.w += T * backgrounds[cam * 4 + 3];
+            }
+            *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
+        } else {
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d)
+                render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
+        }
+        last_ids[pix] = cur_idx;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
+                                const float* opacities, const float* backgrounds,
+                                const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                                int tile_size, int tile_width, int tile_height,
+                                const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                int64_t n_isects, float* render_colors, float* render_alphas,
+                                int32_t* last_ids, sc_stream_t stream) {
+    if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
+    if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
+    if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
+    if ((int64_t)tile_width * tile_size < width || (int64_t)tile_height * tile_size < height) return SC_EINVAL;
+    if (C == 0) return SC_OK;
+    if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return SC_EINVAL;
+    if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return SC_EINVAL;
+    if (C > 65535 || tile_height > 65535) return SC_EINVAL;
+    dim3 grid(tile_width, tile_height, C);
+    const int variant = g_sc_raster_fwd_variant;
+    if (variant == 1 && tile_size == 16 && (D == 3 || D == 4)) {
+        if (D == 4)
+            hipLaunchKernelGGL(raster_fwd_cull_kernel<4>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
+                               colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                               render_alphas, last_ids);
+        else
+            hipLaunchKernelGGL(raster_fwd_cull_kernel<3>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
+                               colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                               render_alphas, last_ids);
+        SC_LAUNCH_CHECK();
+        return SC_OK;
+    }
+    dim3 block(tile_size, tile_size);
+    const size_t shmem = (size_t)tile_size * tile_size * 40;
+    if (D == 4)
+        hipLaunchKernelGGL(raster_fwd_ref_kernel<4>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
+                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                           render_alphas, last_ids);
+    else if (D == 3)
+        hipLaunchKernelGGL(raster_fwd_ref_kernel<3>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
+                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                           render_alphas, last_ids);
+    else
+        hipLaunchKernelGGL(raster_fwd_ref_kernel<0>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
+                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                           render_alphas, last_ids);
+    SC_LAUNCH_CHECK();
+    return SC_OK;
+}

@@ -1,0 +1,60 @@
+// Shared host/device helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/street_crafter_amd.h"
+
+#define SC_WAVE 64
+
+#define SC_LAUNCH_CHECK()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+#define SC_HIP(call)                                        \
+    do {                                                    \
+        hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess) return (int)e__;             \
+    } while (0)
+
+static inline hipStream_t sc_s(sc_stream_t s) { return (hipStream_t)s; }
+
+static inline size_t sc_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// floor(log2(n)) + 1 for n >= 1  (tile_bits / cam_bits)
+static inline int sc_bits_for(int64_t n) {
+    int b = 0;
+    while (n > 0) { ++b; n >>= 1; }
+    return b < 1 ? 1 : b;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int sc_lane() { return (int)(threadIdx.x & 63); }
+
+// inclusive wave scan (64 lanes) of an int
+__device__ __forceinline__ int sc_wave_incl_scan(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (sc_lane() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ long long sc_wave_incl_scan64(long long v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        long long t = __shfl_up(v, d, 64);
+        if (sc_lane() >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float sc_wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long sc_lanemask_lt() {
+    return (1ull << sc_lane()) - 1ull;
+}
+#endif

@@ -1,0 +1,77 @@
+"""One-frame-per-GPU sharding of the novel-view loop with a gather of rendered frames.
+
+The reference renders frames in a plain sequential loop (render.py:64-70: no cross-frame state,
+model read-only under no_grad), single process, single GPU; it has no collective to mirror
+(SURVEY.md 2.2, 8e).  Here: one process per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU for tests), frame f is rendered by rank f % world, and finished
+frames are gathered to rank 0 as uint8 [H,W,3] (7.4 MB at 1920x1280 -- tiny against 7 x 153 GB/s
+of xGMI into the root), asynchronously, so the next frame's raster overlaps the transfer.
+No data-path collective exists besides this gather: the shards are independent (weak scaling).
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
+    """frame f -> rank f % world (round-robin keeps neighbouring cameras on different GPUs)."""
+    return list(range(rank, n_frames, world))
+
+
+def to_uint8_frame(rgb_chw: torch.Tensor) -> torch.Tensor:
+    """[3,H,W] float in [0,1] -> [H,W,3] uint8 (what the reference's visualizer writes to disk)."""
+    return (rgb_chw.detach().clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous()
+
+
+class FrameGatherer:
+    """Gathers one frame per rank per round to `dst`.  `submit()` starts an async gather and
+    returns immediately; `drain()` waits for everything outstanding and returns, on dst, the
+    frames in global frame order."""
+
+    def __init__(self, dst: int = 0, group=None):
+        self.dst = dst
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._pending = []          # (work, round_index, gather_list | None, frame)
+        self._done = {}             # global frame index -> tensor (dst only)
+
+    def submit(self, round_index: int, frame_u8: torch.Tensor):
+        if self.world == 1:
+            self._done[round_index] = frame_u8
+            return
+        glist = None
+        if self.rank == self.dst:
+            glist = [torch.empty_like(frame_u8) for _ in range(self.world)]
+        work = dist.gather(frame_u8, gather_list=glist, dst=self.dst, group=self.group, async_op=True)
+        self._pending.append((work, round_index, glist, frame_u8))
+
+    def drain(self):
+        for work, r, glist, _ in self._pending:
+            work.wait()
+            if glist is not None:
+                for k, f in enumerate(glist):
+                    self._done[r * self.world + k] = f
+        self._pending.clear()
+        if self.rank != self.dst:
+            return []
+        return [self._done[k] for k in sorted(self._done)]
+
+
+def render_sharded(n_frames: int, render_frame: Callable[[int], torch.Tensor], dst: int = 0,
+                   group=None) -> Optional[List[torch.Tensor]]:
+    """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
+    (None elsewhere).  n_frames must be a multiple of the world size (every round is a full
+    gather); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if n_frames % world:
+        raise ValueError(f"n_frames={n_frames} must be a multiple of world size {world}")
+    g = FrameGatherer(dst, group)
+    for r, f in enumerate(frames_for_rank(n_frames, rank, world)):
+        g.submit(r, render_frame(f))
+    frames = g.drain()
+    return frames if rank == dst else None

@@ -1,0 +1,464 @@
+"""gsplat.rendering operator mirror for MI355X.
+
+Same names, argument meaning, return shapes and error behaviour as the six gsplat (v1.0-v1.4
+API family) operators StreetCrafter imports at
+``street_gaussian/models/street_gaussian_renderer.py:204`` and calls at ``:219-280``.  Every op
+launches hand-written HIP kernels through the C ABI (``include/street_crafter_amd.h``) on torch's
+current stream; torch is used only for device memory, the stream handle and autograd wiring.
+There is no CPU path: non-HIP tensors raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+__all__ = ["fully_fused_projection", "isect_tiles", "isect_offset_encode", "spherical_harmonics",
+           "rasterize_to_pixels", "rasterization"]
+
+# "bin"  : tile-bucketed count + in-LDS per-tile sort (default once available)
+# "radix": reference-shaped count -> emit -> device-wide radix sort
+_ISECT_MODE = {"mode": "radix"}
+
+
+def set_isect_mode(mode: str) -> str:
+    assert mode in ("bin", "radix")
+    prev = _ISECT_MODE["mode"]
+    _ISECT_MODE["mode"] = mode
+    return prev
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _req(t: Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); "
+                           "street_crafter_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------
+# a1 fully_fused_projection  (renderer.py:219-232)
+# ------------------------------------------------------------------------------------------
+class _Projection(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                far_plane, radius_clip, calc_compensations):
+        lib = _lib.load()
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+        comps = torch.empty((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
+        _lib.check(lib.sc_projection_fwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N,
+                                         int(width), int(height), float(eps2d), float(near_plane),
+                                         float(far_plane), float(radius_clip), _p(radii), _p(means2d),
+                                         _p(depths), _p(conics), _p(comps), _stream(means)),
+                   "sc_projection_fwd")
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics,
+                              comps if comps is not None else torch.empty(0, device=dev))
+        ctx.dims = (int(width), int(height), float(eps2d), bool(calc_compensations))
+        ctx.mark_non_differentiable(radii)
+        if comps is None:
+            return radii, means2d, depths, conics
+        return radii, means2d, depths, conics, comps
+
+    @staticmethod
+    def backward(ctx, v_radii, v_means2d, v_depths, v_conics, v_comps=None):
+        lib = _lib.load()
+        means, quats, scales, viewmats, Ks, radii, conics, comps = ctx.saved_tensors
+        width, height, eps2d, has_comp = ctx.dims
+        C, N = viewmats.shape[0], means.shape[0]
+        dev = means.device
+
+        def z(t, shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t.contiguous()
+
+        v_means2d = z(v_means2d, (C, N, 2))
+        v_depths = z(v_depths, (C, N))
+        v_conics = z(v_conics, (C, N, 3))
+        if has_comp:
+            v_comps = z(v_comps, (C, N))
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        _lib.check(lib.sc_projection_bwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N, width,
+                                         height, eps2d, _p(radii), _p(conics),
+                                         _p(comps) if has_comp else None, _p(v_means2d), _p(v_depths),
+                                         _p(v_conics), _p(v_comps) if has_comp else None, _p(v_means),
+                                         _p(v_quats), _p(v_scales), _stream(means)),
+                   "sc_projection_bwd")
+        return (v_means if ctx.needs_input_grad[0] else None,
+                v_quats if ctx.needs_input_grad[1] else None,
+                v_scales if ctx.needs_input_grad[2] else None,
+                None, None, None, None, None, None, None, None, None)
+
+
+def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor],
+                           scales: Optional[Tensor], viewmats: Tensor, Ks: Tensor, width: int,
+                           height: int, eps2d: float = 0.3, near_plane: float = 0.01,
+                           far_plane: float = 1e10, radius_clip: float = 0.0, packed: bool = False,
+                           sparse_grad: bool = False, calc_compensations: bool = False):
+    """means [N,3], quats [N,4] (wxyz), scales [N,3], viewmats [C,4,4], Ks [C,3,3] ->
+    (radii i32[C,N], means2d [C,N,2], depths [C,N], conics [C,N,3], compensations [C,N] | None)."""
+    if covars is not None:
+        raise NotImplementedError("covars= is not supported: the reference passes quats/scales "
+                                  "(street_gaussian_renderer.py:219-224)")
+    if packed:
+        raise NotImplementedError("packed=True is not supported: the reference passes packed=False "
+                                  "(street_gaussian_renderer.py:228)")
+    assert quats is not None and scales is not None, "quats and scales are required"
+    means = _req(means, "means")
+    quats = _req(quats, "quats")
+    scales = _req(scales, "scales")
+    viewmats = _req(viewmats, "viewmats")
+    Ks = _req(Ks, "Ks")
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    out = _Projection.apply(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                            far_plane, radius_clip, calc_compensations)
+    if calc_compensations:
+        return out
+    return (*out, None)
+
+
+# ------------------------------------------------------------------------------------------
+# a3 isect_tiles  (renderer.py:243-252)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int,
+                tile_height: int, sort: bool = True, packed: bool = False,
+                n_cameras: Optional[int] = None, camera_ids: Optional[Tensor] = None,
+                gaussian_ids: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (tiles_per_gauss i32[C,N], isect_ids i64[I] (sorted), flatten_ids i32[I])."""
+    if packed:
+        raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
+    lib = _lib.load()
+    means2d = _req(means2d.detach(), "means2d")
+    radii = _req(radii, "radii", torch.int32)
+    depths = _req(depths.detach(), "depths")
+    C, N = radii.shape
+    assert means2d.shape == (C, N, 2), means2d.shape
+    assert depths.shape == (C, N), depths.shape
+    if n_cameras is not None:
+        assert int(n_cameras) == C, (n_cameras, C)
+    dev = means2d.device
+    st = _stream(means2d)
+    tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
+    total_dev = torch.empty(1, dtype=torch.int64, device=dev)
+    mode = _ISECT_MODE["mode"] if sort else "radix"
+    if mode == "bin":
+        res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
+                               tiles_per_gauss, total_dev, st)
+        if res is not None:
+            return res
+    wsb = lib.sc_isect_workspace_bytes(C * N)
+    ws = _ws(wsb, dev)
+    _lib.check(lib.sc_isect_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
+                                  int(tile_height), _p(tiles_per_gauss), _p(total_dev), _p(ws), ws.numel(), st),
+               "sc_isect_count")
+    n_isects = int(total_dev.item())    # the one unavoidable D2H read (sizes the outputs)
+    isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    if n_isects:
+        _lib.check(lib.sc_isect_emit(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
+                                     int(tile_height), _p(tiles_per_gauss), n_isects, _p(isect_ids),
+                                     _p(flatten_ids), _p(ws), ws.numel(), st), "sc_isect_emit")
+        if sort:
+            n_tiles = tile_width * tile_height
+            tile_bits = int(math.floor(math.log2(n_tiles))) + 1
+            cam_bits = int(math.floor(math.log2(C))) + 1
+            tmp_k = torch.empty_like(isect_ids)
+            tmp_v = torch.empty_like(flatten_ids)
+            sws = _ws(lib.sc_radix_sort_workspace_bytes(n_isects), dev)
+            _lib.check(lib.sc_radix_sort_pairs_u64_i32(_p(isect_ids), _p(flatten_ids), _p(tmp_k), _p(tmp_v),
+                                                       n_isects, 32 + tile_bits + cam_bits, _p(sws),
+                                                       sws.numel(), st), "sc_radix_sort_pairs_u64_i32")
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
+                     tiles_per_gauss, total_dev, st):
+    dev = means2d.device
+    offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
+    ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, 0), dev)
+    rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
+                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(total_dev), _p(ws0),
+                                ws0.numel(), st)
+    if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
+        return None
+    _lib.check(rc, "sc_isect_bin_count")
+    n_isects = int(total_dev.item())
+    isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    if n_isects:
+        ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, n_isects), dev)
+        rc = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
+                                   int(tile_height), _p(offsets), n_isects, _p(isect_ids), _p(flatten_ids),
+                                   _p(ws), ws.numel(), st)
+        if rc == -3:
+            return None
+        _lib.check(rc, "sc_isect_bin_sort")
+    return tiles_per_gauss, isect_ids, flatten_ids
+
+
+# ------------------------------------------------------------------------------------------
+# a4 isect_offset_encode  (renderer.py:253)
+# ------------------------------------------------------------------------------------------
+@torch.no_grad()
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    lib = _lib.load()
+    isect_ids = _req(isect_ids, "isect_ids", torch.int64)
+    dev = isect_ids.device
+    offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_isect_offsets(_p(isect_ids), isect_ids.numel(), int(n_cameras), int(tile_width),
+                                    int(tile_height), _p(offsets), _stream(isect_ids)), "sc_isect_offsets")
+    return offsets
+
+
+# ------------------------------------------------------------------------------------------
+# a6 spherical_harmonics  (renderer.py:259)
+# ------------------------------------------------------------------------------------------
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, dirs, coeffs, masks):
+        lib = _lib.load()
+        M = dirs.numel() // 3
+        K = coeffs.shape[-2]
+        colors = torch.empty(dirs.shape, dtype=torch.float32, device=dirs.device)
+        _lib.check(lib.sc_sh_fwd(int(degree), _p(dirs), _p(coeffs), _p(masks), M, K, _p(colors),
+                                 _stream(dirs)), "sc_sh_fwd")
+        ctx.save_for_backward(dirs, coeffs, masks if masks is not None else torch.empty(0, device=dirs.device))
+        ctx.meta = (int(degree), M, K, masks is not None)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = _lib.load()
+        dirs, coeffs, masks = ctx.saved_tensors
+        degree, M, K, has_mask = ctx.meta
+        v_colors = v_colors.contiguous()
+        v_coeffs = torch.empty_like(coeffs)
+        need_dirs = ctx.needs_input_grad[1]
+        v_dirs = torch.empty_like(dirs) if need_dirs else None
+        _lib.check(lib.sc_sh_bwd(degree, _p(dirs), _p(coeffs), _p(masks) if has_mask else None, M, K,
+                                 _p(v_colors), _p(v_coeffs), _p(v_dirs), _stream(dirs)), "sc_sh_bwd")
+        return None, v_dirs, (v_coeffs if ctx.needs_input_grad[2] else None), None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
+                        masks: Optional[Tensor] = None) -> Tensor:
+    """dirs [...,3] (not normalised by the caller, renderer.py:256), coeffs [...,K,3], masks [...]."""
+    assert 0 <= degrees_to_use <= 4, degrees_to_use
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert dirs.shape[:-1] == coeffs.shape[:-2], (dirs.shape, coeffs.shape)
+    assert dirs.shape[-1] == 3 and coeffs.shape[-1] == 3, (dirs.shape, coeffs.shape)
+    dirs = _req(dirs, "dirs")
+    coeffs = _req(coeffs, "coeffs")
+    if masks is not None:
+        assert masks.shape == dirs.shape[:-1], masks.shape
+        if not masks.is_cuda:
+            raise RuntimeError("masks must live on a HIP device")
+        masks = masks.to(torch.uint8).contiguous() if masks.dtype != torch.uint8 else masks.contiguous()
+    return _SphericalHarmonics.apply(int(degrees_to_use), dirs, coeffs, masks)
+
+
+# ------------------------------------------------------------------------------------------
+# a9 rasterize_to_pixels  (renderer.py:267-280)
+# ------------------------------------------------------------------------------------------
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
+                isect_offsets, flatten_ids, absgrad, means2d_obj):
+        lib = _lib.load()
+        C, N = opacities.shape
+        D = colors.shape[-1]
+        th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
+        dev = means2d.device
+        render_colors = torch.empty((C, height, width, D), dtype=torch.float32, device=dev)
+        render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
+        last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev)
+        _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
+                                        _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
+                                        _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+                                        _p(render_colors), _p(render_alphas), _p(last_ids), _stream(means2d)),
+                   "sc_rasterize_fwd")
+        e = torch.empty(0, device=dev)
+        ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,
+                              masks if masks is not None else e, isect_offsets, flatten_ids, render_alphas,
+                              last_ids)
+        ctx.meta = (int(width), int(height), int(tile_size), bool(absgrad), backgrounds is not None,
+                    masks is not None)
+        ctx.means2d_obj = means2d_obj
+        return render_colors, render_alphas
+
+    @staticmethod
+    def backward(ctx, v_render_colors, v_render_alphas):
+        lib = _lib.load()
+        (means2d, conics, colors, opacities, backgrounds, masks, isect_offsets, flatten_ids, render_alphas,
+         last_ids) = ctx.saved_tensors
+        width, height, tile_size, absgrad, has_bg, has_mask = ctx.meta
+        C, N = opacities.shape
+        D = colors.shape[-1]
+        th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
+        dev = means2d.device
+        v_render_colors = v_render_colors.contiguous()
+        v_render_alphas = v_render_alphas.contiguous()
+        v_means2d = torch.zeros_like(means2d)
+        v_conics = torch.zeros_like(conics)
+        v_colors = torch.zeros_like(colors)
+        v_opacities = torch.zeros_like(opacities)
+        v_abs = torch.zeros_like(means2d) if absgrad else None
+        _lib.check(lib.sc_rasterize_bwd(_p(means2d), _p(conics), _p(colors), _p(opacities),
+                                        _p(backgrounds) if has_bg else None, _p(masks) if has_mask else None,
+                                        C, N, D, width, height, tile_size, tw, th, _p(isect_offsets),
+                                        _p(flatten_ids), flatten_ids.numel(), _p(render_alphas), _p(last_ids),
+                                        _p(v_render_colors), _p(v_render_alphas), _p(v_abs), _p(v_means2d),
+                                        _p(v_conics), _p(v_colors), _p(v_opacities), _stream(means2d)),
+                   "sc_rasterize_bwd")
+        if absgrad:
+            # gsplat contract: the tensor object the CALLER passed gets an `.absgrad` attribute
+            # (read at street_gaussian/models/street_gaussian_model.py:505-506)
+            ctx.means2d_obj.tensor.absgrad = v_abs
+        v_bg = None
+        if has_bg and ctx.needs_input_grad[4]:
+            v_bg = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
+        return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None, None)
+
+
+class _AbsgradTarget:
+    """Carries the caller's means2d tensor OBJECT through autograd untouched, so that backward can
+    attach `.absgrad` to it (gsplat's contract, relied on at street_gaussian_model.py:505-506)."""
+    __slots__ = ("tensor",)
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor,
+                        image_width: int, image_height: int, tile_size: int, isect_offsets: Tensor,
+                        flatten_ids: Tensor, backgrounds: Optional[Tensor] = None,
+                        masks: Optional[Tensor] = None, packed: bool = False,
+                        absgrad: bool = False) -> Tuple[Tensor, Tensor]:
+    """-> (render_colors [C,H,W,D], render_alphas [C,H,W,1])."""
+    if packed:
+        raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
+    caller_means2d = means2d
+    means2d_c = _req(means2d, "means2d")
+    conics = _req(conics, "conics")
+    colors = _req(colors, "colors")
+    opacities = _req(opacities, "opacities")
+    isect_offsets = _req(isect_offsets, "isect_offsets", torch.int32)
+    flatten_ids = _req(flatten_ids, "flatten_ids", torch.int32)
+    C, N = opacities.shape
+    D = colors.shape[-1]
+    assert means2d_c.shape == (C, N, 2), means2d_c.shape
+    assert conics.shape == (C, N, 3), conics.shape
+    assert colors.shape == (C, N, D), colors.shape
+    assert isect_offsets.ndim == 3 and isect_offsets.shape[0] == C, isect_offsets.shape
+    th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
+    assert tw * tile_size >= image_width, "image_width must fit in tile_width * tile_size"
+    assert th * tile_size >= image_height, "image_height must fit in tile_height * tile_size"
+    if not 1 <= D <= 32:
+        raise NotImplementedError(f"colour channels must be in 1..32, got {D}")
+    if backgrounds is not None:
+        backgrounds = _req(backgrounds, "backgrounds")
+        assert backgrounds.shape == (C, D), backgrounds.shape
+    if masks is not None:
+        assert masks.shape == isect_offsets.shape, masks.shape
+        if not masks.is_cuda:
+            raise RuntimeError("masks must live on a HIP device")
+        masks = masks.to(torch.uint8).contiguous()
+
+    return _Rasterize.apply(means2d_c, conics, colors, opacities, backgrounds, masks, int(image_width),
+                            int(image_height), int(tile_size), isect_offsets, flatten_ids, bool(absgrad),
+                            _AbsgradTarget(caller_means2d))
+
+
+# ------------------------------------------------------------------------------------------
+# a13 rasterization  (imported at renderer.py:204, never called there): thin composition
+# ------------------------------------------------------------------------------------------
+def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+                  viewmats: Tensor, Ks: Tensor, width: int, height: int, near_plane: float = 0.01,
+                  far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
+                  sh_degree: Optional[int] = None, packed: bool = False, tile_size: int = 16,
+                  backgrounds: Optional[Tensor] = None, render_mode: str = "RGB",
+                  sparse_grad: bool = False, absgrad: bool = False, rasterize_mode: str = "classic",
+                  channel_chunk: int = 32, distributed: bool = False, camera_model: str = "pinhole",
+                  covars: Optional[Tensor] = None):
+    """Composition of a1 -> a3 -> a4 -> a6 -> a9 with gsplat's `rasterization` signature.
+    means [N,3], quats [N,4], scales [N,3], opacities [N], colors [N,D] | [N,K,3] (with sh_degree),
+    viewmats [C,4,4], Ks [C,3,3].  Returns (render_colors [C,H,W,*], render_alphas [C,H,W,1], meta)."""
+    assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
+    assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
+    if camera_model != "pinhole" or distributed or covars is not None:
+        raise NotImplementedError("only pinhole, single-process, quats/scales input is supported")
+    C = viewmats.shape[0]
+    N = means.shape[0]
+    aa = rasterize_mode == "antialiased"
+    radii, means2d, depths, conics, comps = fully_fused_projection(
+        means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, calc_compensations=aa)
+    opac = opacities.reshape(1, N).expand(C, N)
+    if comps is not None:
+        opac = opac * comps
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                          tile_height, packed=False, n_cameras=C)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    if sh_degree is None:
+        cols = colors.reshape(1, N, -1).expand(C, N, -1) if colors.dim() == 2 else colors
+    else:
+        campos = torch.linalg.inv(viewmats)[:, :3, 3]
+        dirs = means[None, :, :] - campos[:, None, :]
+        shs = colors.reshape(1, N, -1, 3).expand(C, N, -1, 3)
+        cols = spherical_harmonics(sh_degree, dirs, shs, masks=radii > 0)
+        cols = torch.clamp_min(cols + 0.5, 0.0)
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[..., None]], dim=-1)
+        if backgrounds is not None:
+            backgrounds = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device)], dim=-1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[..., None]
+        if backgrounds is not None:
+            backgrounds = torch.zeros(C, 1, device=backgrounds.device)
+    render_colors, render_alphas = rasterize_to_pixels(means2d, conics, cols.contiguous(), opac.contiguous(),
+                                                       width, height, tile_size, isect_offsets, flatten_ids,
+                                                       backgrounds=backgrounds, packed=False, absgrad=absgrad)
+    if render_mode in ("ED", "RGB+ED"):
+        render_colors = torch.cat([render_colors[..., :-1],
+                                   render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+    meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+            "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+            "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+            "width": width, "height": height, "tile_size": tile_size, "n_cameras": C}
+    return render_colors, render_alphas, meta

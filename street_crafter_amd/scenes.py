@@ -1,0 +1,113 @@
+"""Seeded synthetic scenes and cameras for benchmarks and parity tests.
+
+"S-100k" / "S-1M" of SURVEY.md section 8(d) / BASELINE.md section 2: a pin-hole camera at the
+origin looking down +z (OpenCV convention, like the w2c the reference passes at
+``street_gaussian/models/street_gaussian_renderer.py:215``) over N random Gaussians.
+Tensors are produced on the CPU from a ``torch.Generator`` so that the GPU box, this
+container and the oracle all see bit-identical inputs.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+SEED = 20250404
+
+
+@dataclass
+class Scene:
+    means: torch.Tensor       # f32[N,3]  world xyz            (pc.get_xyz)
+    quats: torch.Tensor       # f32[N,4]  wxyz                 (pc.get_rotation)
+    scales: torch.Tensor      # f32[N,3]  already exp()-ed     (pc.get_scaling)
+    opacities: torch.Tensor   # f32[N,1]  already sigmoid()-ed (pc.get_opacity)
+    sh: torch.Tensor          # f32[N,K,3]                     (pc.get_features)
+    sh_degree: int
+
+    def to(self, device):
+        return Scene(self.means.to(device), self.quats.to(device), self.scales.to(device),
+                     self.opacities.to(device), self.sh.to(device), self.sh_degree)
+
+    @property
+    def n(self):
+        return self.means.shape[0]
+
+
+@dataclass
+class Camera:
+    viewmat: torch.Tensor     # f32[4,4] row-major world->camera
+    K: torch.Tensor           # f32[3,3]
+    width: int
+    height: int
+    znear: float = 0.001      # street_gaussian/utils/camera_utils.py:47-48
+    zfar: float = 1000.0
+
+    @property
+    def camera_center(self):
+        R = self.viewmat[:3, :3].double()
+        t = self.viewmat[:3, 3].double()
+        return (-(R.T @ t)).float()
+
+    def to(self, device):
+        return Camera(self.viewmat.to(device), self.K.to(device), self.width, self.height,
+                      self.znear, self.zfar)
+
+
+def make_camera(width=1920, height=1280, fx=2050.0, fy=2050.0, yaw=0.0, shift=(0.0, 0.0, 0.0)):
+    """Identity view by default; `yaw` (radians, about +y) and `shift` give per-frame jitter."""
+    c, s = math.cos(yaw), math.sin(yaw)
+    R = torch.tensor([[c, 0.0, -s], [0.0, 1.0, 0.0], [s, 0.0, c]], dtype=torch.float64)
+    t = -R @ torch.tensor(shift, dtype=torch.float64)
+    V = torch.eye(4, dtype=torch.float64)
+    V[:3, :3] = R
+    V[:3, 3] = t
+    K = torch.tensor([[fx, 0.0, width / 2.0], [0.0, fy, height / 2.0], [0.0, 0.0, 1.0]])
+    return Camera(V.float(), K.float(), int(width), int(height))
+
+
+def make_scene(n, sh_degree=1, seed=SEED, x_span=0.55, y_span=0.37, z_range=(2.0, 80.0),
+               scale_range=(0.005, 0.15)):
+    g = torch.Generator().manual_seed(seed)
+
+    def U(lo, hi, *shape):
+        return torch.rand(*shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+    z = U(z_range[0], z_range[1], n)
+    x = z * U(-x_span, x_span, n)
+    y = z * U(-y_span, y_span, n)
+    means = torch.stack([x, y, z], dim=-1)
+    scales = torch.exp(U(math.log(scale_range[0]), math.log(scale_range[1]), n, 3))
+    q = torch.randn(n, 4, generator=g, dtype=torch.float32)
+    quats = q / q.norm(dim=-1, keepdim=True)
+    opac = torch.sigmoid(torch.randn(n, 1, generator=g, dtype=torch.float32) * 1.5)
+    K = (sh_degree + 1) ** 2
+    sh = torch.randn(n, K, 3, generator=g, dtype=torch.float32)
+    sh[:, 1:, :] *= 0.3
+    return Scene(means.contiguous(), quats.contiguous(), scales.contiguous(),
+                 opac.contiguous(), sh.contiguous(), sh_degree)
+
+
+def make_edge_case_scene(n=4096, seed=7):
+    """Projection edge cases for the golden fixtures: behind the camera,
+    nearer than znear, farther than zfar, enormous scales, needle-thin scales, off-screen,
+    un-normalised and tiny quaternions, duplicates."""
+    sc = make_scene(n, sh_degree=1, seed=seed, x_span=0.6, y_span=0.42, z_range=(0.5, 60.0))
+    m = sc.means.clone()
+    s = sc.scales.clone()
+    q = sc.quats.clone()
+    k = n // 16
+    m[0 * k:1 * k, 2] *= -1.0                      # behind
+    m[1 * k:2 * k, 2] = 0.0005                     # < znear
+    m[2 * k:3 * k, 2] = 1500.0                     # > zfar
+    s[3 * k:4 * k] *= 200.0                        # enormous
+    s[4 * k:5 * k, 0] = 1e-7                       # needle
+    s[5 * k:6 * k] = 1e-9                          # sub-pixel everything
+    q[6 * k:7 * k] *= 37.5                         # un-normalised
+    q[7 * k:8 * k] *= 1e-3
+    m[8 * k:9 * k, 0] = m[8 * k:9 * k, 2] * 3.0    # far off-screen
+    m[9 * k:10 * k] = m[9 * k]                     # duplicates (equal depth keys)
+    s[9 * k:10 * k] = s[9 * k]
+    q[9 * k:10 * k] = q[9 * k]
+    m[10 * k:11 * k, 2] = 5.0                      # identical depths, different xy
+    return Scene(m.contiguous(), q.contiguous(), s.contiguous(), sc.opacities, sc.sh, 1)

@@ -1,0 +1,106 @@
+"""No-GPU checks of the drop-in boundary: the shared library builds/loads, exports every symbol
+declared in include/*.h, the ctypes table matches the header, and the Python operators refuse
+CPU tensors (there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from street_crafter_amd import build
+    build.build()
+    from street_crafter_amd import _lib
+    return _lib.load()
+
+
+def _declared():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            src = open(os.path.join(inc, f)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from street_crafter_amd import _lib
+    declared = _declared()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in include/ but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+
+
+def test_library_info_and_errors(lib):
+    assert b"gfx950" in lib.sc_target_arch()
+    assert lib.sc_error_string(0) == b"ok"
+    assert b"invalid" in lib.sc_error_string(-1)
+    assert b"workspace" in lib.sc_error_string(-2)
+    assert lib.sc_set_option(b"no_such_option", 1) == -1
+    prev = lib.sc_set_option(b"raster_fwd", 0)
+    assert lib.sc_set_option(b"raster_fwd", prev) == 0
+
+
+def test_argument_validation_without_gpu(lib):
+    # rejected before any launch: nothing here touches a device
+    assert lib.sc_projection_fwd(None, None, None, None, None, 1, 8, 0, 0, 0.3, 0.01, 1e10, 0.0,
+                                 None, None, None, None, None, None) == -1
+    assert lib.sc_projection_fwd(None, None, None, None, None, 1, 8, 64, 64, 0.3, 0.01, 1e10, 0.0,
+                                 None, None, None, None, None, None) == -1        # null pointers
+    assert lib.sc_sh_fwd(5, None, None, None, 4, 36, None, None) == -1              # degree > 4
+    assert lib.sc_sh_fwd(3, None, None, None, 4, 9, None, None) == -1               # K < 16
+    assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 33, 64, 64, 16, 4, 4,
+                                None, None, 0, None, None, None, None) == -1        # D > 32
+    assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 3, 65, 64, 16, 4, 4,
+                                None, None, 0, None, None, None, None) == -1        # tiles too few
+    assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 10, 65, None, 0, None) == -1
+    assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 1, 40, None, 0, None) == 0   # n<=1 no-op
+    assert lib.sc_knn3_mean_dist2(None, 0, None, None, 0, None) == 0
+    assert lib.sc_knn_workspace_bytes(1000) >= 1000 * 36
+    assert lib.sc_isect_workspace_bytes(1_000_000) >= (1_000_000 // 256) * 8
+
+
+def test_operators_refuse_cpu_tensors(lib):
+    from gsplat.rendering import (fully_fused_projection, isect_offset_encode, isect_tiles,
+                                  rasterize_to_pixels, spherical_harmonics, rasterization)  # noqa: F401
+    from simple_knn._C import distCUDA2
+    n = 8
+    with pytest.raises(RuntimeError, match="HIP device"):
+        fully_fused_projection(torch.zeros(n, 3), None, torch.zeros(n, 4), torch.zeros(n, 3),
+                               torch.eye(4)[None], torch.eye(3)[None], 64, 64)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        spherical_harmonics(1, torch.zeros(1, n, 3), torch.zeros(1, n, 4, 3))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        isect_tiles(torch.zeros(1, n, 2), torch.zeros(1, n, dtype=torch.int32), torch.zeros(1, n), 16, 4, 4)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        isect_offset_encode(torch.zeros(3, dtype=torch.int64), 1, 4, 4)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        rasterize_to_pixels(torch.zeros(1, n, 2), torch.zeros(1, n, 3), torch.zeros(1, n, 3), torch.zeros(1, n),
+                            64, 64, 16, torch.zeros(1, 4, 4, dtype=torch.int32), torch.zeros(0, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        distCUDA2(torch.zeros(n, 3))
+    with pytest.raises(NotImplementedError):
+        fully_fused_projection(torch.zeros(n, 3), torch.zeros(n, 3, 3), None, None, torch.eye(4)[None],
+                               torch.eye(3)[None], 64, 64)
+
+
+def test_product_path_never_imports_oracle():
+    """The oracle is test infrastructure: no product module may import it."""
+    bad = []
+    for pkg in ("street_crafter_amd", "gsplat", "simple_knn"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,183 @@
+"""CPU tests of the oracle itself: against vectors produced by the REFERENCE's own code
+(sh_eval_ref.npz, psnr_ref.npz; generator tools/make_golden.py), against independent
+implementations (scipy cKDTree, float64 torch autograd restatement) and against its own committed
+fixtures (drift guard)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gsplat_oracle as O
+from oracle import gsplat_torch as OT
+from oracle import knn_oracle as KO
+from street_crafter_amd.scenes import make_camera, make_scene
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---- pinned against reference code ---------------------------------------------------------
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+def test_sh_matches_reference_eval_sh(golden_dir, deg):
+    """oracle SH == street_gaussian/utils/sh_utils.py:57-112 eval_sh on unit directions."""
+    g = _load(golden_dir, "sh_eval_ref.npz")
+    K = (deg + 1) ** 2
+    got = O.spherical_harmonics(deg, g["dirs"].astype(np.float32), g["coeffs"][:, :K].astype(np.float32))
+    np.testing.assert_allclose(got, g[f"deg{deg}"], rtol=0, atol=3e-6)
+    # the op normalises internally: scaling the directions must not change the result
+    got2 = O.spherical_harmonics(deg, (g["dirs"] * 7.5).astype(np.float32),
+                                 g["coeffs"][:, :K].astype(np.float32))
+    np.testing.assert_allclose(got2, g[f"deg{deg}"], rtol=0, atol=3e-6)
+    gt = OT.spherical_harmonics(deg, torch.from_numpy(g["dirs"]), torch.from_numpy(g["coeffs"][:, :K]))
+    np.testing.assert_allclose(gt.numpy(), g[f"deg{deg}"], rtol=0, atol=1e-12)
+
+
+def test_psnr_matches_reference_definition(golden_dir):
+    g = _load(golden_dir, "psnr_ref.npz")
+    assert abs(O.psnr(g["img1"], g["img2"]) - float(g["psnr"])) < 1e-4
+
+
+# ---- independent implementations -----------------------------------------------------------
+def test_knn_oracle_vs_ckdtree():
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(3000, 3)).astype(np.float32)
+    got = KO.dist_cuda2(pts)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    ref = (d[:, 1:] ** 2).mean(axis=1)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9)
+
+
+def test_knn_oracle_edge_cases(golden_dir):
+    g = _load(golden_dir, "knn_small.npz")
+    for k in ("pts", "dup", "line", "tiny"):
+        key = "out" if k == "pts" else f"out_{k}"
+        np.testing.assert_array_equal(KO.dist_cuda2(g[k]), g[key])
+    assert (g["out_dup"][100:140] == 0).all()            # duplicates count as distance 0
+    assert (g["out_tiny"] > 1e38).all()                  # < 4 points: a FLT_MAX term per missing neighbour
+    assert KO.dist_cuda2(np.zeros((0, 3), np.float32)).shape == (0,)
+    np.testing.assert_allclose(g["out_line"][1:-1], (0.0625 + 0.0625 + 0.25) / 3, rtol=1e-6)
+
+
+def test_projection_vs_float64_restatement():
+    sc = make_scene(2000, seed=3)
+    cam = make_camera()
+    r, m2, d, con, comp = O.fully_fused_projection(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(),
+                                                   cam.viewmat.numpy(), cam.K.numpy(), cam.width, cam.height,
+                                                   near_plane=cam.znear, far_plane=cam.zfar)
+    rt, m2t, dt, cont, compt = OT.fully_fused_projection(sc.means.double(), sc.quats.double(),
+                                                        sc.scales.double(), cam.viewmat.double(),
+                                                        cam.K.double(), cam.width, cam.height,
+                                                        near_plane=cam.znear, far_plane=cam.zfar)
+    same = r == rt.numpy()
+    assert same.mean() > 0.999          # ceil() can flip on a 1-ulp difference; never more
+    vis = (r > 0) & same
+    np.testing.assert_allclose(m2[vis], m2t.numpy()[vis], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(d[vis], dt.numpy()[vis], rtol=1e-6)
+    np.testing.assert_allclose(con[vis], cont.numpy()[vis], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(comp[vis], compt.numpy()[vis], rtol=2e-3, atol=1e-6)
+
+
+def test_rasterize_numpy_vs_torch_restatement(golden_dir):
+    g = _load(golden_dir, "pipeline_small.npz")
+    rc, ra = OT.rasterize_to_pixels(torch.from_numpy(g["means2d"])[None].double(),
+                                    torch.from_numpy(g["conics"])[None].double(),
+                                    torch.from_numpy(g["colors"])[None].double(),
+                                    torch.from_numpy(g["opacities"])[None].double(), int(g["in_width"]),
+                                    int(g["in_height"]), 16, torch.from_numpy(g["isect_offsets"]),
+                                    torch.from_numpy(g["flatten_ids"]))
+    ok = ~g["unstable"]
+    np.testing.assert_allclose(rc.numpy()[ok], g["render_colors"][ok], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(ra.numpy()[ok], g["render_alphas"][ok], rtol=0, atol=2e-5)
+    assert g["unstable"].mean() < 0.01
+
+
+def test_rasterize_scalar_loop_matches_vectorised(golden_dir):
+    """The literal per-pixel loop of SURVEY A.5 on a few pixels == the vectorised oracle."""
+    g = _load(golden_dir, "pipeline_small.npz")
+    W, H = int(g["in_width"]), int(g["in_height"])
+    offs = g["isect_offsets"].reshape(-1)
+    fids = g["flatten_ids"]
+    F = np.float32
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        x, y = int(rng.integers(W)), int(rng.integers(H))
+        t = (y // 16) * (W // 16) + x // 16
+        s, e = offs[t], (offs[t + 1] if t + 1 < offs.size else fids.size)
+        T, cur, out = F(1), 0, np.zeros(4, F)
+        px, py = F(x) + F(0.5), F(y) + F(0.5)
+        for k in range(s, e):
+            n = fids[k]
+            dx, dy = g["means2d"][n, 0] - px, g["means2d"][n, 1] - py
+            a, b, c = g["conics"][n]
+            sigma = F(0.5) * ((a * dx) * dx + (c * dy) * dy) + (b * dx) * dy
+            alpha = min(F(0.999), g["opacities"][n] * np.exp(-sigma, dtype=F))
+            if sigma < 0 or alpha < F(1.0 / 255.0):
+                continue
+            nT = T * (F(1) - alpha)
+            if nT <= F(1e-4):
+                break
+            out = out + g["colors"][n] * (alpha * T)
+            cur, T = k, nT
+        np.testing.assert_array_equal(out, g["render_colors"][0, y, x])
+        assert F(1) - T == g["render_alphas"][0, y, x, 0]
+        assert cur == g["last_ids"][0, y, x]
+
+
+# ---- structure / invariants ----------------------------------------------------------------
+def test_isect_invariants(golden_dir):
+    g = _load(golden_dir, "pipeline_small.npz")
+    ids, fids, offs = g["isect_ids"], g["flatten_ids"], g["isect_offsets"]
+    assert (np.diff(ids) >= 0).all()
+    assert ids.shape[0] == g["tiles_per_gauss"].sum()
+    # stable: equal keys keep ascending flat index
+    eq = np.diff(ids) == 0
+    assert (np.diff(fids.astype(np.int64))[eq] > 0).all()
+    tile = (ids >> 32) & ((1 << O.tile_bits(8 * 6)) - 1)
+    flat = offs.reshape(-1)
+    for t in range(48):
+        s = flat[t]
+        e = flat[t + 1] if t + 1 < 48 else ids.shape[0]
+        assert (tile[s:e] == t).all()
+    # depth part of the key is the fp32 bit pattern of the Gaussian's depth
+    np.testing.assert_array_equal((ids & 0xFFFFFFFF).astype(np.uint32), g["depths"][fids].view(np.uint32))
+    # unsorted emission order: gaussian-major, row-major over the rectangle
+    _, u_ids, u_f = O.isect_tiles(g["means2d"][None], g["radii"][None], g["depths"][None], 16, 8, 6, sort=False)
+    assert (np.diff(u_f.astype(np.int64)) >= 0).all()
+    order = np.argsort(u_ids, kind="stable")
+    np.testing.assert_array_equal(u_ids[order], ids)
+    np.testing.assert_array_equal(u_f[order], fids)
+
+
+def test_offsets_empty_and_trailing():
+    ids = np.array([(3 << 32) | 5, (3 << 32) | 9, (7 << 32) | 1], dtype=np.int64)
+    off = O.isect_offset_encode(ids, 1, 4, 3).reshape(-1)
+    np.testing.assert_array_equal(off, [0, 0, 0, 0, 2, 2, 2, 2, 3, 3, 3, 3])
+    assert (O.isect_offset_encode(np.zeros(0, np.int64), 1, 4, 3) == 0).all()
+
+
+def test_oracle_fixture_drift(golden_dir):
+    """Re-running the oracle reproduces the committed fixtures bit for bit."""
+    g = _load(golden_dir, "proj_small.npz")
+    r = O.fully_fused_projection(g["means"], g["quats"], g["scales"], g["viewmat"], g["K"], int(g["width"]),
+                                 int(g["height"]), near_plane=float(g["near"]), far_plane=float(g["far"]))
+    for got, name in zip(r, ("radii", "means2d", "depths", "conics", "compensations")):
+        np.testing.assert_array_equal(got, g[name])
+    # every edge-case class is present in the fixture
+    assert (g["radii"] == 0).sum() > 1000 and (g["radii"] > 0).sum() > 1000
+    p = _load(golden_dir, "pipeline_small.npz")
+    out = O.render_frame(p["in_means"], p["in_quats"], p["in_scales"], p["in_opacities"], p["in_sh"],
+                         p["in_viewmat"], p["in_K"], int(p["in_width"]), int(p["in_height"]), 1,
+                         near_plane=float(p["in_near"]), far_plane=float(p["in_far"]))
+    for k in ("radii", "isect_ids", "flatten_ids", "isect_offsets", "render_colors", "render_alphas", "last_ids"):
+        np.testing.assert_array_equal(out[k], p[k])
+
+
+def test_algorithmic_bytes_formula():
+    from street_crafter_amd.pipeline import algorithmic_bytes
+    n, i = 1_000_000, 8_000_000
+    assert algorithmic_bytes(n, i, 1920, 1280) == 197 * n + 88 * i + 24 * 1920 * 1280 + 4 * 9600
+    assert algorithmic_bytes(n, 0, 1920, 1280, sh_bases=16) - 24 * 1920 * 1280 - 4 * 9600 == 341 * n
