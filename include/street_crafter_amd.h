@@ -94,17 +94,20 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
 /* Fused tile-bucketed path: produces exactly what count + emit + stable sort + offset-encode
  * produce (bit-identical isect_ids / flatten_ids / offsets) with one bucket pass and one
  * in-LDS sort per tile.  Two calls because the caller must size the outputs in between:
- *   sc_isect_bin_count : tiles_per_gauss, per-tile offsets (= isect_offset_encode result) and total
- *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted
+ *   sc_isect_bin_count : tiles_per_gauss, per-tile offsets (= isect_offset_encode result) and
+ *                        meta_dev[0] = total intersections, meta_dev[1] = largest per-tile count
+ *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted (max_per_tile = meta_dev[1] read back)
+ * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384 or one tile holds more than
+ * 9216 intersections; the caller then takes the count/emit/radix-sort route.
  */
 size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_isects);
 int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
                        int tile_size, int tile_width, int tile_height,
-                       int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* total_dev,
+                       int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* meta_dev /* [2] */,
                        void* workspace, size_t ws_bytes, sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
-                      const int32_t* isect_offsets, int64_t n_isects,
+                      const int32_t* isect_offsets, int64_t n_isects, int64_t max_per_tile,
                       int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
 

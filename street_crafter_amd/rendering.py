@@ -209,24 +209,28 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
                      tiles_per_gauss, total_dev, st):
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
+    meta_dev = torch.empty(2, dtype=torch.int64, device=dev)
     ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, 0), dev)
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
-                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(total_dev), _p(ws0),
+                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev), _p(ws0),
                                 ws0.numel(), st)
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
     _lib.check(rc, "sc_isect_bin_count")
-    n_isects = int(total_dev.item())
+    n_isects, max_per_tile = (int(v) for v in meta_dev.tolist())   # the one D2H read (sizes the outputs)
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     if n_isects:
         ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, n_isects), dev)
         rc = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
-                                   int(tile_height), _p(offsets), n_isects, _p(isect_ids), _p(flatten_ids),
-                                   _p(ws), ws.numel(), st)
+                                   int(tile_height), _p(offsets), n_isects, max_per_tile, _p(isect_ids),
+                                   _p(flatten_ids), _p(ws), ws.numel(), st)
         if rc == -3:
             return None
         _lib.check(rc, "sc_isect_bin_sort")
+    # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
+    # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
+    isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
@@ -236,6 +240,10 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
 @torch.no_grad()
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     lib = _lib.load()
+    cached = getattr(isect_ids, "_sc_offsets", None)
+    if cached is not None and cached[1:] == (int(n_cameras), int(tile_width), int(tile_height),
+                                              isect_ids._version):
+        return cached[0]
     isect_ids = _req(isect_ids, "isect_ids", torch.int64)
     dev = isect_ids.device
     offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=dev)
