@@ -96,9 +96,15 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
  * in-LDS sort per tile.  Two calls because the caller must size the outputs in between:
  *   sc_isect_bin_count : tiles_per_gauss, per-tile offsets (= isect_offset_encode result) and
  *                        meta_dev[0] = total intersections, meta_dev[1] = largest per-tile count
- *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted (max_per_tile = meta_dev[1] read back)
- * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384 or one tile holds more than
- * 9216 intersections; the caller then takes the count/emit/radix-sort route.
+ *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted.  `capacity` = elements the output buffers
+ *                        (and the workspace) were sized for, `tile_capacity` = largest per-tile
+ *                        count the caller provisioned LDS for.  The kernels read meta_dev themselves
+ *                        and do NOTHING when meta_dev[0] > capacity or meta_dev[1] > tile_capacity,
+ *                        so a caller may launch with predicted sizes before it has read meta_dev
+ *                        back (no GPU idle bubble) and retry with exact sizes if the prediction
+ *                        was too small.
+ * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384 or tile_capacity > 9216;
+ * the caller then takes the count/emit/radix-sort route.
  */
 size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_isects);
 int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
@@ -107,8 +113,8 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
                        void* workspace, size_t ws_bytes, sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
-                      const int32_t* isect_offsets, int64_t n_isects, int64_t max_per_tile,
-                      int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
+                      const int32_t* isect_offsets, const int64_t* meta_dev, int64_t capacity,
+                      int64_t tile_capacity, int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
 
 /* ---- a4: offsets (renderer.py:253) ---------------------------------------------------- */

@@ -151,8 +151,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ depths, int64_t CN, int N, float tile_size, int tile_width,
     int tile_height, int n_buckets, const int32_t* __restrict__ offsets,
+    const int64_t* __restrict__ meta, int64_t capacity, int64_t tile_capacity,
     unsigned* __restrict__ cursor, uint2* __restrict__ bucket) {
     extern __shared__ unsigned lds[];
+    // the caller may have sized the buffers from a prediction: do nothing if they are too small
+    if (meta[0] > capacity || meta[1] > tile_capacity) return;
     unsigned* hist = lds;               // [n_buckets] counts, then running local cursors
     unsigned* gbase = lds + n_buckets;  // [n_buckets] global start of this workgroup's slice
     for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
@@ -250,8 +253,8 @@ __device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ s
 }
 
 __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
-    const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets, int n_isects,
-    int tiles_per_cam, int tile_bits, int id_bits, int cap, int64_t* __restrict__ isect_ids,
+    const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
+    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int id_bits, int cap, int64_t* __restrict__ isect_ids,
     int32_t* __restrict__ flatten_ids) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);
@@ -261,9 +264,10 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
     __shared__ unsigned diff_s;
     __shared__ int tie_s;
 
+    if (meta[0] > capacity || meta[1] > (int64_t)cap) return;    // undersized prediction: caller retries
     const int b = blockIdx.x;
     const int s = offsets[b];
-    const int e = (b + 1 < n_buckets) ? offsets[b + 1] : n_isects;
+    const int e = (b + 1 < n_buckets) ? offsets[b + 1] : (int)meta[0];
     const int n = e - s;
     if (n <= 0) return;
     const int t = threadIdx.x;
@@ -366,22 +370,24 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
 
 extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C,
                                  int N, int tile_size, int tile_width, int tile_height,
-                                 const int32_t* isect_offsets, int64_t n_isects, int64_t max_per_tile,
-                                 int64_t* isect_ids, int32_t* flatten_ids, void* workspace,
-                                 size_t ws_bytes, sc_stream_t stream) {
-    if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0 || n_isects < 0)
+                                 const int32_t* isect_offsets, const int64_t* meta_dev, int64_t capacity,
+                                 int64_t tile_capacity, int64_t* isect_ids, int32_t* flatten_ids,
+                                 void* workspace, size_t ws_bytes, sc_stream_t stream) {
+    if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0 || capacity < 0 ||
+        tile_capacity < 0)
         return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
     const int64_t nb64 = (int64_t)C * tile_width * tile_height;
-    if (nb64 > BIN_MAX_BUCKETS || CN > 0x7fffffffLL || n_isects > 0x7fffffffLL) return SC_EUNSUPPORTED;
-    if (n_isects == 0 || CN == 0) return SC_OK;
+    if (nb64 > BIN_MAX_BUCKETS || CN > 0x7fffffffLL || capacity > 0x7fffffffLL) return SC_EUNSUPPORTED;
+    if (capacity == 0 || CN == 0) return SC_OK;
     const int nb = (int)nb64;
-    // LDS capacity of one tile-sort workgroup: two 8-byte copies of the bucket
-    if (max_per_tile < 0) return SC_EINVAL;
-    if (max_per_tile > 9216) return SC_EUNSUPPORTED;              // 2 x 8 B x records must fit 144 KiB
-    const int cap = (int)((max_per_tile + 255) / 256 * 256 > 256 ? (max_per_tile + 255) / 256 * 256 : 256);
-    if (!means2d || !radii || !depths || !isect_offsets || !flatten_ids || !workspace) return SC_EINVAL;
-    if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, n_isects)) return SC_EWORKSPACE;
+    // LDS capacity of one tile-sort workgroup: two 8-byte copies of the bucket must fit 144 KiB
+    if (tile_capacity > 9216) return SC_EUNSUPPORTED;
+    int cap = (int)((tile_capacity + 255) / 256 * 256);
+    if (cap < 256) cap = 256;
+    if (!means2d || !radii || !depths || !isect_offsets || !meta_dev || !flatten_ids || !workspace)
+        return SC_EINVAL;
+    if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, capacity)) return SC_EWORKSPACE;
     hipStream_t s = sc_s(stream);
     unsigned char* ws = (unsigned char*)workspace;
     unsigned* cursor = (unsigned*)(ws + bin_counts_bytes(nb));
@@ -389,7 +395,8 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     SC_HIP(hipMemsetAsync(cursor, 0, (size_t)nb * 4, s));
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, depths,
-                       CN, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, cursor, bucket);
+                       CN, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, meta_dev, capacity,
+                       (int64_t)cap, cursor, bucket);
     SC_LAUNCH_CHECK();
     const int tiles_per_cam = tile_width * tile_height;
     const int tile_bits = sc_bits_for(tiles_per_cam);
@@ -401,7 +408,7 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
         attr_set = true;
     }
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16, s, (const uint2*)bucket,
-                       isect_offsets, nb, (int)n_isects, tiles_per_cam, tile_bits, id_bits, cap, isect_ids,
+                       isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, id_bits, cap, isect_ids,
                        flatten_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;

@@ -92,9 +92,9 @@ __global__ void raster_bwd_kernel(
                 const float2 bc = bc_s[t];
                 ca = a.w; cb = bc.x; cc = bc.y; opac = a.z;
                 dx = a.x - px; dy = a.y - py;
-                const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
-                vis = sc_fast_exp(-sigma);
-                alpha = fminf(SC_ALPHA_MAX, opac * vis);
+                const float sigma = sc_sigma(ca, cb, cc, dx, dy);
+                vis = sc_vis(sigma);
+                alpha = sc_alpha(opac, vis);
                 if (sigma < 0.f || alpha < SC_ALPHA_MIN) valid = false;
             }
             if (!__any(valid)) continue;

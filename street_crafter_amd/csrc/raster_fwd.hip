@@ -90,16 +90,16 @@ __global__ void raster_fwd_ref_kernel(
             const float4 a = xyoa_s[t];
             const float2 bc = bc_s[t];
             const float dx = a.x - px, dy = a.y - py;
-            const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
-            const float alpha = fminf(SC_ALPHA_MAX, a.z * sc_fast_exp(-sigma));
+            const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
+            const float alpha = sc_alpha(a.z, sc_vis(sigma));
             if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
-            const float next_T = T * (1.0f - alpha);
+            const float next_T = sc_next_T(T, alpha);
             if (next_T <= SC_T_EPS) { done = true; break; }
-            const float vis = alpha * T;
+            const float vis = __fmul_rn(alpha, T);
             const float* c = colors + (int64_t)id_s[t] * D;
 #pragma unroll
             for (int d = 0; d < ND; ++d)
-                if (CDIM > 0 || d < D) pix_out[d] += c[d] * vis;
+                if (CDIM > 0 || d < D) pix_out[d] = __fmaf_rn(c[d], vis, pix_out[d]);
             cur_idx = batch_start + t;
             T = next_T;
         }
@@ -254,17 +254,17 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
             const float4 a = xyoa_s[t];
             const float4 bc = bck_s[t];
             const float dx = a.x - px, dy = a.y - py;
-            const float sigma = 0.5f * (a.w * dx * dx + bc.y * dy * dy) + bc.x * dx * dy;
-            const float alpha = fminf(SC_ALPHA_MAX, a.z * sc_fast_exp(-sigma));
+            const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
+            const float alpha = sc_alpha(a.z, sc_vis(sigma));
             if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
-            const float next_T = T * (1.0f - alpha);
+            const float next_T = sc_next_T(T, alpha);
             if (next_T <= SC_T_EPS) { done = true; break; }
-            const float vis = alpha * T;
+            const float vis = __fmul_rn(alpha, T);
             const float4 c = col_s[t];
-            pix_out[0] += c.x * vis;
-            pix_out[1] += c.y * vis;
-            pix_out[2] += c.z * vis;
-            if (CDIM > 3) pix_out[3] += c.w * vis;
+            pix_out[0] = __fmaf_rn(c.x, vis, pix_out[0]);
+            pix_out[1] = __fmaf_rn(c.y, vis, pix_out[1]);
+            pix_out[2] = __fmaf_rn(c.z, vis, pix_out[2]);
+            if (CDIM > 3) pix_out[3] = __fmaf_rn(c.w, vis, pix_out[3]);
             cur_idx = __float_as_int(bc.z);
             T = next_T;
         }

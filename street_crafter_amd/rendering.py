@@ -22,7 +22,7 @@ __all__ = ["fully_fused_projection", "isect_tiles", "isect_offset_encode", "sphe
 
 # "bin"  : tile-bucketed count + in-LDS per-tile sort (default once available)
 # "radix": reference-shaped count -> emit -> device-wide radix sort
-_ISECT_MODE = {"mode": "radix"}
+_ISECT_MODE = {"mode": "bin"}
 
 
 def set_isect_mode(mode: str) -> str:
@@ -205,6 +205,13 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     return tiles_per_gauss, isect_ids, flatten_ids
 
 
+# Sizes seen on the previous call with the same shape: lets the bucket scatter + per-tile sort be
+# enqueued with predicted buffer sizes BEFORE the host has read the counts back, so the GPU never
+# idles on the host round-trip.  The kernels verify the prediction on the device (see
+# sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
+_BIN_PREDICTION = {}
+
+
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
                      tiles_per_gauss, total_dev, st):
     dev = means2d.device
@@ -217,17 +224,39 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
     _lib.check(rc, "sc_isect_bin_count")
-    n_isects, max_per_tile = (int(v) for v in meta_dev.tolist())   # the one D2H read (sizes the outputs)
-    isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
-    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-    if n_isects:
-        ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, n_isects), dev)
-        rc = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
-                                   int(tile_height), _p(offsets), n_isects, max_per_tile, _p(isect_ids),
-                                   _p(flatten_ids), _p(ws), ws.numel(), st)
+    meta_host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    meta_host.copy_(meta_dev, non_blocking=True)
+    ready = torch.cuda.Event()
+    ready.record()
+
+    def launch(capacity, tile_capacity):
+        ids = torch.empty(capacity, dtype=torch.int64, device=dev)
+        fids = torch.empty(capacity, dtype=torch.int32, device=dev)
+        ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, capacity), dev)
+        r = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
+                                  int(tile_height), _p(offsets), _p(meta_dev), capacity, tile_capacity,
+                                  _p(ids), _p(fids), _p(ws), ws.numel(), st)
+        return r, ids, fids
+
+    key = (dev.index, C, N, int(tile_size), int(tile_width), int(tile_height))
+    pred = _BIN_PREDICTION.get(key)
+    rc, ids, fids = (None, None, None)
+    if pred is not None:
+        rc, ids, fids = launch(*pred)
+        if rc == -3:
+            rc = None
+        elif rc != 0:
+            _lib.check(rc, "sc_isect_bin_sort")
+    ready.synchronize()        # the one D2H read of a frame (sizes the outputs); GPU already has work
+    n_isects, max_per_tile = int(meta_host[0]), int(meta_host[1])
+    if rc is None or n_isects > pred[0] or max_per_tile > pred[1]:
+        rc, ids, fids = launch(n_isects, max_per_tile)
         if rc == -3:
             return None
         _lib.check(rc, "sc_isect_bin_sort")
+    # next call: 12.5 % head-room over what this frame needed
+    _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, min(9216, max_per_tile + max_per_tile // 8 + 64))
+    isect_ids, flatten_ids = ids[:n_isects], fids[:n_isects]
     # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
     # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
     isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
