@@ -18,8 +18,16 @@ extern "C" const char* sc_error_string(int code) {
     return "street_crafter_amd: unknown error";
 }
 
+int g_sc_debug[4] = {0, 0, 0, 0};
+
 extern "C" int sc_set_option(const char* key, int value) {
     if (!key) return SC_EINVAL;
+    if (strncmp(key, "debug", 5) == 0 && key[5] >= '0' && key[5] <= '3' && key[6] == 0) {
+        if (value < 0) return SC_EINVAL;
+        const int prev = g_sc_debug[key[5] - '0'];
+        g_sc_debug[key[5] - '0'] = value;
+        return prev;
+    }
     if (strcmp(key, "raster_fwd") == 0) {
         if (value < 0 || value > 1) return SC_EINVAL;
         const int prev = g_sc_raster_fwd_variant;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
     const float* __restrict__ depths, int64_t CN, int N, float tile_size, int tile_width,
     int tile_height, int n_buckets, const int32_t* __restrict__ offsets,
     const int64_t* __restrict__ meta, int64_t capacity, int64_t tile_capacity,
-    unsigned* __restrict__ cursor, uint2* __restrict__ bucket) {
+    unsigned* __restrict__ cursor, uint2* __restrict__ bucket, int dbg) {
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[1] > tile_capacity) return;
@@ -182,16 +182,17 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
         const unsigned c = hist[b];
-        if (c) gbase[b] = (unsigned)offsets[b] + atomicAdd(&cursor[b], c);
+        if (c) gbase[b] = (unsigned)offsets[b] + ((dbg & 4) ? 0u : atomicAdd(&cursor[b], c));
         hist[b] = 0;
     }
     __syncthreads();
+    if (dbg & 2) return;
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
         const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
         walk_rect(rr[k], cc[k], bb[k], tile_width, dd[k], (unsigned)i, [&](int b, unsigned d, unsigned id) {
             const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
-            bucket[slot] = make_uint2(d, id);
+            if (!(dbg & 1)) bucket[slot] = make_uint2(d, id);
         });
     }
 }
@@ -254,7 +255,8 @@ __device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ s
 
 __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
     const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
-    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int id_bits, int cap, int64_t* __restrict__ isect_ids,
+    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int id_bits, int cap,
+    const unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
     int32_t* __restrict__ flatten_ids) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);
@@ -266,6 +268,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
 
     if (meta[0] > capacity || meta[1] > (int64_t)cap) return;    // undersized prediction: caller retries
     const int b = blockIdx.x;
+    if (needs_radix && !needs_radix[b]) return;                  // already sorted by tile_bucket_sort_kernel
     const int s = offsets[b];
     const int e = (b + 1 < n_buckets) ? offsets[b + 1] : (int)meta[0];
     const int n = e - s;
@@ -327,6 +330,111 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
     }
 }
 
+// ---- per-tile interpolation (bucket) sort: the common path ---------------------------------------
+// The depth keys of one tile are spread over 2n buckets by a MONOTONE map of their bit pattern
+// (so bucket order == key order for any input, NaN and negative patterns included); one counting
+// pass groups the records by bucket, then every record finds its final rank by counting the
+// smaller (depth, id) keys inside its own bucket (expected occupancy < 1).  One histogram + one
+// scan + one scatter + one short rank loop instead of 4-7 ballot-ranked radix passes.  A tile
+// whose keys pile up in one bucket (occupancy > BS_MAX_OCC, e.g. hundreds of equal depths) is
+// flagged and left to tile_sort_kernel.
+constexpr int BS_MAX_OCC = 48;
+
+__global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
+    const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
+    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int cap,
+    unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
+    int32_t* __restrict__ flatten_ids) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);      // [cap]
+    unsigned* boff = reinterpret_cast<unsigned*>(smem + (size_t)cap * 8);     // [2*cap + 1]
+    __shared__ unsigned red_lo[TS_WAVES], red_hi[TS_WAVES], red_sum[TS_WAVES], red_occ[TS_WAVES];
+
+    if (meta[0] > capacity || meta[1] > (int64_t)cap) return;    // undersized prediction: caller retries
+    const int b = blockIdx.x;
+    const int s = offsets[b];
+    const int e = (b + 1 < n_buckets) ? offsets[b + 1] : (int)meta[0];
+    const int n = e - s;
+    if (n <= 0) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long cam = b / tiles_per_cam, tile = b % tiles_per_cam;
+    const long long hi_key = (cam << (32 + tile_bits)) | (tile << 32);
+
+    // number of sub-buckets: 2n rounded up to a multiple of 256 (fits: n <= cap, boff holds 2*cap+1)
+    const int nbk = ((2 * n + TS_THREADS - 1) / TS_THREADS) * TS_THREADS;
+    const int per_thread = nbk / TS_THREADS;
+    for (int i = t; i <= nbk; i += TS_THREADS) boff[i] = 0;
+
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = t; i < n; i += TS_THREADS) {
+        const unsigned d = bucket[s + i].x;
+        lo = min(lo, d);
+        hi = max(hi, d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if (lane == 0) { red_lo[wave] = lo; red_hi[wave] = hi; }
+    __syncthreads();
+    lo = min(min(red_lo[0], red_lo[1]), min(red_lo[2], red_lo[3]));
+    hi = max(max(red_hi[0], red_hi[1]), max(red_hi[2], red_hi[3]));
+    const float scale = (float)nbk / ((float)(hi - lo) + 1.0f);
+    auto sub_bucket = [&](unsigned d) -> int {
+        const int v = (int)((float)(d - lo) * scale);     // monotone in d
+        return min(v, nbk - 1);
+    };
+
+    // histogram
+    for (int i = t; i < n; i += TS_THREADS) atomicAdd(&boff[sub_bucket(bucket[s + i].x)], 1u);
+    __syncthreads();
+    // exclusive scan over nbk counters: thread t owns per_thread consecutive counters
+    unsigned sum = 0, occ = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        const unsigned c = boff[t * per_thread + k];
+        sum += c;
+        occ = max(occ, c);
+    }
+    const unsigned incl = (unsigned)sc_wave_incl_scan((int)sum);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) occ = max(occ, (unsigned)__shfl_xor((int)occ, o, 64));
+    if (lane == 63) red_sum[wave] = incl;
+    if (lane == 0) red_occ[wave] = occ;
+    __syncthreads();
+    occ = max(max(red_occ[0], red_occ[1]), max(red_occ[2], red_occ[3]));
+    if (occ > BS_MAX_OCC) {                     // wave-uniform and workgroup-uniform
+        if (t == 0) needs_radix[b] = 1;
+        return;
+    }
+    unsigned run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < TS_WAVES; ++w) if (w < wave) run += red_sum[w];
+    for (int k = 0; k < per_thread; ++k) {      // counts -> bucket starts (used as running cursors)
+        const unsigned c = boff[t * per_thread + k];
+        boff[t * per_thread + k] = run;
+        run += c;
+    }
+    __syncthreads();
+    // scatter: after this pass boff[j] is the END of sub-bucket j (== start of j+1)
+    for (int i = t; i < n; i += TS_THREADS) {
+        const uint2 r = bucket[s + i];
+        const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
+        B[slot] = ((unsigned long long)r.x << 32) | r.y;
+    }
+    __syncthreads();
+    // rank inside the sub-bucket by (depth bits, flat id) and write the final records
+    for (int p = t; p < n; p += TS_THREADS) {
+        const unsigned long long key = B[p];
+        const int j = sub_bucket((unsigned)(key >> 32));
+        const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
+        unsigned r = beg;
+        for (unsigned q = beg; q < end; ++q) r += (B[q] < key) ? 1u : 0u;
+        if (isect_ids) isect_ids[s + r] = hi_key | (long long)(key >> 32);
+        flatten_ids[s + r] = (int32_t)(unsigned)key;
+    }
+}
+
 }  // namespace
 
 static inline size_t bin_counts_bytes(int n_buckets) { return sc_align_up((size_t)n_buckets * 4, 256); }
@@ -336,7 +444,7 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
     (void)CN;
     const int64_t nb = (int64_t)C * tile_width * tile_height;
     if (nb <= 0 || nb > BIN_MAX_BUCKETS) return 256;
-    return 2 * bin_counts_bytes((int)nb) + sc_align_up((size_t)(n_isects > 0 ? n_isects : 0) * 8, 256) + 256;
+    return 3 * bin_counts_bytes((int)nb) + sc_align_up((size_t)(n_isects > 0 ? n_isects : 0) * 8, 256) + 256;
 }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N, int tile_size,
@@ -391,12 +499,13 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     hipStream_t s = sc_s(stream);
     unsigned char* ws = (unsigned char*)workspace;
     unsigned* cursor = (unsigned*)(ws + bin_counts_bytes(nb));
-    uint2* bucket = (uint2*)(ws + 2 * bin_counts_bytes(nb));
-    SC_HIP(hipMemsetAsync(cursor, 0, (size_t)nb * 4, s));
+    unsigned char* needs_radix = ws + 2 * bin_counts_bytes(nb);
+    uint2* bucket = (uint2*)(ws + 3 * bin_counts_bytes(nb));
+    SC_HIP(hipMemsetAsync(cursor, 0, 2 * bin_counts_bytes(nb), s));   // cursor + needs_radix flags
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, depths,
                        CN, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, meta_dev, capacity,
-                       (int64_t)cap, cursor, bucket);
+                       (int64_t)cap, cursor, bucket, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
     const int tiles_per_cam = tile_width * tile_height;
     const int tile_bits = sc_bits_for(tiles_per_cam);
@@ -404,12 +513,19 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   144 * 1024));
+                                   152 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
+    // common path: interpolation sort; it flags the (rare) tiles it leaves to the radix kernel
+    hipLaunchKernelGGL(tile_bucket_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16 + 16, s,
+                       (const uint2*)bucket, isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, cap,
+                       needs_radix, isect_ids, flatten_ids);
+    SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16, s, (const uint2*)bucket,
-                       isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, id_bits, cap, isect_ids,
-                       flatten_ids);
+                       isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, id_bits, cap,
+                       (const unsigned char*)needs_radix, isect_ids, flatten_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
     int width, int height, int tile_width, int tile_height,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids) {
+    int32_t* __restrict__ last_ids, int dbg) {
     constexpr int B = 256;
     __shared__ float4 xyoa_s[B];      // mx, my, opac, conic.a
     __shared__ float4 bck_s[B];       // conic.b, conic.c, k (sorted index, as int bits), -
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
         }
         __syncthreads();
         // ---- blend ---------------------------------------------------------------------------
+        if (dbg & 1) bsz = 0;
         for (int t = 0; (t < bsz) && !done; ++t) {
             const float4 a = xyoa_s[t];
             const float4 bc = bck_s[t];
@@ -311,12 +312,12 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
             hipLaunchKernelGGL(raster_fwd_cull_kernel<4>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
                                colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
                                tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
-                               render_alphas, last_ids);
+                               render_alphas, last_ids, g_sc_debug[1]);
         else
             hipLaunchKernelGGL(raster_fwd_cull_kernel<3>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
                                colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
                                tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
-                               render_alphas, last_ids);
+                               render_alphas, last_ids, g_sc_debug[1]);
         SC_LAUNCH_CHECK();
         return SC_OK;
     }

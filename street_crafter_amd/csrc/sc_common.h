@@ -18,6 +18,10 @@
         if (e__ != hipSuccess) return (int)e__;             \
     } while (0)
 
+// Diagnostic knobs (sc_set_option("debug0".."debug3", v)); 0 in production.  A non-zero value makes
+// a kernel SKIP part of its work so that the part can be priced; outputs are then invalid.
+extern int g_sc_debug[4];
+
 static inline hipStream_t sc_s(sc_stream_t s) { return (hipStream_t)s; }
 
 static inline size_t sc_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

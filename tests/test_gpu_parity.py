@@ -149,6 +149,35 @@ def test_isect_multi_camera_vs_oracle(ops, n_cams):
     np.testing.assert_array_equal(_np(off), e_off)
 
 
+@pytest.mark.parametrize("mode", ["radix", "bin"])
+@pytest.mark.parametrize("n_depths", [1, 3, 4000])
+def test_isect_depth_ties_keep_index_order(ops, mode, n_depths):
+    """Equal depth keys inside a tile must stay in ascending flat-index order (stable sort).
+    n_depths = 1 / 3: thousands of identical keys per tile (forces the bin path's radix fallback,
+    and its tie re-sort); 4000: mixed.  Also a negative-depth block (bit-pattern order)."""
+    from street_crafter_amd import rendering
+    rng = np.random.default_rng(n_depths)
+    N, W, H = 6000, 96, 64
+    tw, th = 6, 4
+    m2 = rng.uniform(-8, 104, size=(1, N, 2)).astype(np.float32)
+    r = rng.integers(0, 40, size=(1, N)).astype(np.int32)
+    levels = rng.uniform(1.0, 50.0, size=n_depths).astype(np.float32)
+    d = levels[rng.integers(0, n_depths, size=(1, N))]
+    if n_depths == 4000:
+        d[0, :500] *= -1.0
+    e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, tw, th)
+    prev = rendering.set_isect_mode(mode)
+    try:
+        tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, tw, th)
+        off = ops.isect_offset_encode(ids, 1, tw, th)
+    finally:
+        rendering.set_isect_mode(prev)
+    np.testing.assert_array_equal(_np(tpg), e_tpg)
+    np.testing.assert_array_equal(_np(ids), e_ids)
+    np.testing.assert_array_equal(_np(fids), e_f)
+    np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, tw, th))
+
+
 def test_radix_sort_large_stable(ops):
     """4.2 M pairs with heavy key duplication vs torch.sort(stable=True) (same device)."""
     from street_crafter_amd import _lib
