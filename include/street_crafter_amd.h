@@ -106,6 +106,8 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
  * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384 or tile_capacity > 9216;
  * the caller then takes the count/emit/radix-sort route.
  */
+/* n_isects < 0: bytes of the count-phase workspace (shared by both calls; holds the spatial order
+ * of the visible Gaussians); n_isects >= 0: bytes of the sort-phase workspace for that capacity. */
 size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_isects);
 int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
                        int tile_size, int tile_width, int tile_height,
@@ -113,8 +115,10 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
                        void* workspace, size_t ws_bytes, sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
-                      const int32_t* isect_offsets, const int64_t* meta_dev, int64_t capacity,
-                      int64_t tile_capacity, int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
+                      const int32_t* isect_offsets, const int64_t* meta_dev,
+                      const void* count_workspace /* the one sc_isect_bin_count filled */,
+                      int64_t capacity, int64_t tile_capacity,
+                      int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
 
 /* ---- a4: offsets (renderer.py:253) ---------------------------------------------------- */
@@ -158,9 +162,18 @@ size_t sc_knn_workspace_bytes(int64_t n);
 int sc_knn3_mean_dist2(const float* points, int64_t n, float* out, void* workspace,
                        size_t ws_bytes, sc_stream_t stream);
 
+/* ---- frame export for the multi-GPU gather (no reference counterpart: the reference's visualizer
+ *      does .cpu().numpy() per frame, street_gaussian/visualizers/street_gaussian_visualizer.py:82-101)
+ * rgb: f32 pixels with `channel_stride` floats per pixel (>= 3; e.g. 4 for the RGB+depth image);
+ * out: uint8 [n_pixels, 3] = clamp(rgb,0,1)*255 rounded half up. */
+int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8_t* out,
+                   sc_stream_t stream);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled (default)
+ *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
+ *       when non-zero; 0 in production)
  * Returns the previous value, or SC_EINVAL for an unknown key. */
 int sc_set_option(const char* key, int value);
 

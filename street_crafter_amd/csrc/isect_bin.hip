@@ -5,19 +5,23 @@
 // The reference-shaped route (isect.hip + radix_sort.hip) moves every (key, value) pair through
 // HBM once per radix pass: 6 x 24 B x I.  The sort key is (camera, tile, depth bits), and the
 // number of (camera, tile) buckets is small (9600 at 1920x1280), so instead:
-//   1. bin_count   : per-workgroup LDS histogram over (camera, tile) -> global counts -> exclusive
-//                    scan = isect_offsets (exactly isect_offset_encode's lower bounds) + total + max
-//   2. bin_scatter : each workgroup reserves a slice of every bucket it touches with ONE global
-//                    atomic per (workgroup, bucket), then drops 8-byte (depth bits, flat id) records
-//                    into its slices (order inside a bucket is arbitrary)
-//   3. tile_sort   : one workgroup per bucket sorts its records in LDS and writes the final
-//                    isect_ids / flatten_ids.  The required order is (depth bits, flat id): a stable
-//                    sort of gaussian-major emission order breaks depth ties by ascending flat id.
-//                    Depth ties inside one tile are rare, so the common path radix-sorts the
-//                    significant depth bits only (stable LSD passes ranked by wave ballots); a tile
-//                    that does contain a tie is re-sorted on the full (depth, id) key.
-// HBM traffic: ~(8 + 8 + 12) B x I instead of ~144 B x I.  Integer work only: results are
-// bit-identical to the reference-shaped route (tests compare both against the oracle).
+//   1. bin_count      : per-workgroup LDS histograms -> global per-bucket counts -> exclusive scan
+//                       = isect_offsets (exactly isect_offset_encode's lower bounds), total, max.
+//                       The same pass histograms the visible Gaussians by the tile of their
+//                       CENTRE and a small counting sort (center_scatter) orders them spatially.
+//   2. bin_scatter    : walks the Gaussians in that spatial order, so the 4096 Gaussians of a
+//                       workgroup touch a compact strip of buckets: it reserves a slice of each
+//                       bucket it touches with ONE global atomic per (workgroup, bucket) and drops
+//                       8-byte (depth bits, flat id) records into its slices; records of one bucket
+//                       arrive in long runs, which is what makes the stores coalesce (in arrival
+//                       order of the Gaussians the same stores ran ~3x slower).
+//   3. tile_bucket_sort: one workgroup per bucket: interpolation sort in LDS on (depth bits, id);
+//                       degenerate tiles (many equal depths) fall back to tile_sort (ballot-ranked
+//                       stable LSD radix passes).
+// The required order is (depth bits, flat id): a stable sort of gaussian-major emission order
+// breaks depth ties by ascending flat id.  Integer work only: results are bit-identical to the
+// reference-shaped route (tests compare both against the oracle).
+// HBM traffic: ~(8 + 8 + 12) B x I instead of ~144 B x I.
 #include "sc_common.h"
 
 #pragma clang fp contract(off)
@@ -76,12 +80,18 @@ __device__ __forceinline__ void walk_rect(const Rect& r, int cnt, int bucket_bas
     }
 }
 
+// ---- pass 1: counts -----------------------------------------------------------------------------
+// counts[b]  += number of rectangles covering bucket b          (-> isect_offsets)
+// ccounts[b] += number of visible Gaussians whose CENTRE tile is b (-> spatial order)
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, int N,
     float tile_size, int tile_width, int tile_height, int n_buckets,
-    int32_t* __restrict__ tiles_per_gauss, unsigned* __restrict__ counts) {
-    extern __shared__ unsigned hist[];   // [n_buckets]
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
+    int32_t* __restrict__ tiles_per_gauss, unsigned* __restrict__ counts,
+    unsigned* __restrict__ ccounts) {
+    extern __shared__ unsigned lds[];
+    unsigned* hist = lds;                 // [n_buckets]
+    unsigned* chist = lds + n_buckets;    // [n_buckets]
+    for (int b = threadIdx.x; b < 2 * n_buckets; b += BIN_THREADS) lds[b] = 0;
     __syncthreads();
     const int T = tile_width * tile_height;
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
@@ -96,88 +106,141 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
             cnt = (r.y1 - r.y0) * (r.x1 - r.x0);
             tiles_per_gauss[i] = cnt;
             bbase = (int)(i / N) * T;
+            if (cnt > 0) {
+                // centre of the (non-empty) rectangle: a tile the Gaussian is filed under
+                const int cx = (r.x0 + r.x1 - 1) >> 1, cy = (r.y0 + r.y1 - 1) >> 1;
+                atomicAdd(&chist[bbase + cy * tile_width + cx], 1u);
+            }
         }
-        walk_rect(r, cnt, bbase, tile_width, 0u, 0u, [&](int bucket, unsigned, unsigned) { atomicAdd(&hist[bucket], 1u); });
+        walk_rect(r, cnt, bbase, tile_width, 0u, 0u,
+                  [&](int bucket, unsigned, unsigned) { atomicAdd(&hist[bucket], 1u); });
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
+        const unsigned c = hist[b], cc = chist[b];
+        if (c) atomicAdd(&counts[b], c);
+        if (cc) atomicAdd(&ccounts[b], cc);
+    }
+}
+
+// single workgroup: out = exclusive scan of counts; meta[0] = total, meta[1] = max count.
+// Thread t owns `per` consecutive counters (one pass, one block scan).
+__global__ __launch_bounds__(1024) void bin_scan_kernel(const unsigned* __restrict__ counts, int n_buckets,
+                                                        int32_t* __restrict__ out,
+                                                        int64_t* __restrict__ meta) {
+    __shared__ long long wave_tot[16];
+    __shared__ unsigned wave_max[16];
+    const int t = threadIdx.x, lane = sc_lane(), wave = t >> 6;
+    const int per = (n_buckets + 1023) / 1024;
+    const int beg = t * per, end = min(beg + per, n_buckets);
+    long long sum = 0;
+    unsigned mx = 0;
+    for (int i = beg; i < end; ++i) {
+        const unsigned c = counts[i];
+        sum += c;
+        mx = max(mx, c);
+    }
+    const long long incl = sc_wave_incl_scan64(sum);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) wave_max[wave] = mx;
+    __syncthreads();
+    long long run = incl - sum, tot = 0;
+    unsigned m = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) run += wave_tot[w];
+        tot += wave_tot[w];
+        m = max(m, wave_max[w]);
+    }
+    for (int i = beg; i < end; ++i) {
+        const unsigned c = counts[i];
+        out[i] = (int32_t)run;
+        run += c;
+    }
+    if (t == 0) { meta[0] = tot; meta[1] = (long long)m; }
+}
+
+// ---- spatial order: counting sort of the visible Gaussians by centre tile -------------------------
+__global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
+    const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
+    const int32_t* __restrict__ radii, int64_t CN, int N, float tile_size, int tile_width,
+    int tile_height, int n_buckets, const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor,
+    int32_t* __restrict__ perm) {
+    extern __shared__ unsigned lds[];
+    unsigned* hist = lds;               // [n_buckets]
+    unsigned* gbase = lds + n_buckets;  // [n_buckets]
+    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
+    __syncthreads();
+    const int T = tile_width * tile_height;
+    const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
+    int cb[BIN_GPT];
+#pragma unroll
+    for (int k = 0; k < BIN_GPT; ++k) {
+        const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+        cb[k] = -1;
+        if (i < CN && tiles_per_gauss[i] > 0) {
+            const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
+            const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, tile_width, tile_height);
+            const int cx = (r.x0 + r.x1 - 1) >> 1, cy = (r.y0 + r.y1 - 1) >> 1;
+            cb[k] = (int)(i / N) * T + cy * tile_width + cx;
+            atomicAdd(&hist[cb[k]], 1u);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
         const unsigned c = hist[b];
-        if (c) atomicAdd(&counts[b], c);
+        if (c) gbase[b] = (unsigned)cstart[b] + atomicAdd(&ccursor[b], c);
+        hist[b] = 0;
     }
-}
-
-// single workgroup: offsets = exclusive scan of counts; meta[0] = total, meta[1] = max count
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const unsigned* __restrict__ counts, int n_buckets,
-                                                        int32_t* __restrict__ offsets,
-                                                        int64_t* __restrict__ meta) {
-    __shared__ long long wave_tot[16];
-    __shared__ unsigned wave_max[16];
-    __shared__ long long carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    const int lane = sc_lane(), wave = threadIdx.x >> 6;
-    unsigned mx = 0;
-    for (int base = 0; base < n_buckets; base += 1024) {
-        const int i = base + threadIdx.x;
-        const unsigned c = (i < n_buckets) ? counts[i] : 0u;
-        mx = max(mx, c);
-        const long long incl = sc_wave_incl_scan64((long long)c);
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        long long pre = carry_s, tot = 0;
-        for (int w = 0; w < 16; ++w) {
-            const long long s = wave_tot[w];
-            if (w < wave) pre += s;
-            tot += s;
-        }
-        if (i < n_buckets) offsets[i] = (int32_t)(pre + incl - c);
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += tot;
-        __syncthreads();
-    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
-    if (lane == 0) wave_max[wave] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned m = 0;
-        for (int w = 0; w < 16; ++w) m = max(m, wave_max[w]);
-        meta[0] = carry_s;
-        meta[1] = (long long)m;
+    for (int k = 0; k < BIN_GPT; ++k) {
+        const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+        if (cb[k] >= 0) perm[gbase[cb[k]] + atomicAdd(&hist[cb[k]], 1u)] = (int32_t)i;
     }
 }
 
+// ---- pass 2: records ------------------------------------------------------------------------------
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    const float* __restrict__ depths, int64_t CN, int N, float tile_size, int tile_width,
+    const float* __restrict__ depths, const int32_t* __restrict__ perm,
+    const int64_t* __restrict__ n_visible, int N, float tile_size, int tile_width,
     int tile_height, int n_buckets, const int32_t* __restrict__ offsets,
     const int64_t* __restrict__ meta, int64_t capacity, int64_t tile_capacity,
     unsigned* __restrict__ cursor, uint2* __restrict__ bucket, int dbg) {
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[1] > tile_capacity) return;
+    const int64_t M = n_visible[0];
+    const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
+    if (base >= M) return;
     unsigned* hist = lds;               // [n_buckets] counts, then running local cursors
     unsigned* gbase = lds + n_buckets;  // [n_buckets] global start of this workgroup's slice
     for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
     __syncthreads();
     const int T = tile_width * tile_height;
-    const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
     Rect rr[BIN_GPT];
     int cc[BIN_GPT], bb[BIN_GPT];
-    unsigned dd[BIN_GPT];
+    unsigned dd[BIN_GPT], ii[BIN_GPT];
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
-        const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+        // consecutive lanes take consecutive Gaussians of the spatial order
+        const int64_t j = base + (int64_t)k * BIN_THREADS + threadIdx.x;
         rr[k] = {0, 0, 0, 0};
-        cc[k] = 0; bb[k] = 0; dd[k] = 0;
-        if (i < CN) {
+        cc[k] = 0; bb[k] = 0; dd[k] = 0; ii[k] = 0;
+        if (j < M) {
+            const int64_t i = perm[j];
             const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
             rr[k] = tile_rect(m.x, m.y, radii[i], tile_size, tile_width, tile_height);
             cc[k] = (rr[k].y1 - rr[k].y0) * (rr[k].x1 - rr[k].x0);
             bb[k] = (int)(i / N) * T;
             dd[k] = __float_as_uint(depths[i]);
+            ii[k] = (unsigned)i;
         }
-        walk_rect(rr[k], cc[k], bb[k], tile_width, 0u, 0u, [&](int b, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
+        walk_rect(rr[k], cc[k], bb[k], tile_width, 0u, 0u,
+                  [&](int b, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
@@ -189,15 +252,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
     if (dbg & 2) return;
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
-        const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
-        walk_rect(rr[k], cc[k], bb[k], tile_width, dd[k], (unsigned)i, [&](int b, unsigned d, unsigned id) {
+        walk_rect(rr[k], cc[k], bb[k], tile_width, dd[k], ii[k], [&](int b, unsigned d, unsigned id) {
             const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
             if (!(dbg & 1)) bucket[slot] = make_uint2(d, id);
         });
     }
 }
 
-// ---- per-tile LDS sort -----------------------------------------------------------------------
+// ---- per-tile LDS sort: radix fallback -------------------------------------------------------------
 constexpr int TS_THREADS = 256;
 constexpr int TS_WAVES = 4;
 
@@ -293,21 +355,21 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
 
     unsigned long long* src = A;
     unsigned long long* dst = B;
-    // common path: stable LSD passes over the significant depth bits only
+    // stable LSD passes over the significant depth bits only ...
     for (int done = 0; done < sig;) {
         const int bits = min(8, sig - done);
         ts_pass(src, dst, n, chunk, 32 + done, bits, h, wtot);
         unsigned long long* tmp = src; src = dst; dst = tmp;
         done += bits;
     }
-    // any two neighbours with the same depth bits? (ties must be ordered by flat id)
+    // ... any two neighbours with the same depth bits? (ties must be ordered by flat id)
     int tie = 0;
     for (int i = t; i + 1 < n; i += TS_THREADS)
         tie |= ((unsigned)(src[i] >> 32) == (unsigned)(src[i + 1] >> 32));
     if (tie) tie_s = 1;
     __syncthreads();
     if (tie_s) {
-        // rare path: full (depth, id) key.  LSD: id bits first, then the depth bits again.
+        // full (depth, id) key.  LSD: id bits first, then the depth bits again.
         for (int done = 0; done < id_bits;) {
             const int bits = min(8, id_bits - done);
             ts_pass(src, dst, n, chunk, done, bits, h, wtot);
@@ -331,13 +393,13 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
 }
 
 // ---- per-tile interpolation (bucket) sort: the common path ---------------------------------------
-// The depth keys of one tile are spread over 2n buckets by a MONOTONE map of their bit pattern
-// (so bucket order == key order for any input, NaN and negative patterns included); one counting
-// pass groups the records by bucket, then every record finds its final rank by counting the
-// smaller (depth, id) keys inside its own bucket (expected occupancy < 1).  One histogram + one
-// scan + one scatter + one short rank loop instead of 4-7 ballot-ranked radix passes.  A tile
-// whose keys pile up in one bucket (occupancy > BS_MAX_OCC, e.g. hundreds of equal depths) is
-// flagged and left to tile_sort_kernel.
+// The depth keys of one tile are spread over 2n sub-buckets by a MONOTONE map of their bit
+// pattern (so sub-bucket order == key order for any input, NaN and negative patterns included);
+// one counting pass groups the records by sub-bucket, then every record finds its final rank by
+// counting the smaller (depth, id) keys inside its own sub-bucket (expected occupancy < 1).  One
+// histogram + one scan + one scatter + one short rank loop instead of 4-7 ballot-ranked radix
+// passes.  A tile whose keys pile up in one sub-bucket (occupancy > BS_MAX_OCC, e.g. hundreds of
+// equal depths) is flagged and left to tile_sort_kernel.
 constexpr int BS_MAX_OCC = 48;
 
 __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
@@ -403,14 +465,14 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     if (lane == 0) red_occ[wave] = occ;
     __syncthreads();
     occ = max(max(red_occ[0], red_occ[1]), max(red_occ[2], red_occ[3]));
-    if (occ > BS_MAX_OCC) {                     // wave-uniform and workgroup-uniform
+    if (occ > BS_MAX_OCC) {                     // workgroup-uniform
         if (t == 0) needs_radix[b] = 1;
         return;
     }
     unsigned run = incl - sum;
 #pragma unroll
     for (int w = 0; w < TS_WAVES; ++w) if (w < wave) run += red_sum[w];
-    for (int k = 0; k < per_thread; ++k) {      // counts -> bucket starts (used as running cursors)
+    for (int k = 0; k < per_thread; ++k) {      // counts -> sub-bucket starts (used as running cursors)
         const unsigned c = boff[t * per_thread + k];
         boff[t * per_thread + k] = run;
         run += c;
@@ -437,19 +499,34 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
 
 }  // namespace
 
+// ---- host side --------------------------------------------------------------------------------
+// count-phase workspace (must be handed to BOTH calls):
+//   counts[nb] | ccounts[nb] | ccursor[nb] | cstart[nb] (i32) | cmeta[2] (i64) | perm[CN] (i32)
+// sort-phase workspace:
+//   cursor[nb] | needs_radix[nb bytes, padded] | records uint2[capacity]
 static inline size_t bin_counts_bytes(int n_buckets) { return sc_align_up((size_t)n_buckets * 4, 256); }
+
+struct BinCountLayout { size_t counts, ccounts, ccursor, cstart, cmeta, perm, total; };
+static BinCountLayout bin_count_layout(int64_t CN, int nb) {
+    BinCountLayout L;
+    const size_t cb = bin_counts_bytes(nb);
+    L.counts = 0; L.ccounts = cb; L.ccursor = 2 * cb; L.cstart = 3 * cb; L.cmeta = 4 * cb;
+    L.perm = 4 * cb + 256;
+    L.total = L.perm + sc_align_up((size_t)(CN > 0 ? CN : 0) * 4, 256);
+    return L;
+}
 
 extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height,
                                                int64_t n_isects) {
-    (void)CN;
     const int64_t nb = (int64_t)C * tile_width * tile_height;
     if (nb <= 0 || nb > BIN_MAX_BUCKETS) return 256;
-    return 3 * bin_counts_bytes((int)nb) + sc_align_up((size_t)(n_isects > 0 ? n_isects : 0) * 8, 256) + 256;
+    if (n_isects < 0) return bin_count_layout(CN, (int)nb).total;    // count-phase workspace
+    return 2 * bin_counts_bytes((int)nb) + sc_align_up((size_t)n_isects * 8, 256) + 256;
 }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N, int tile_size,
                                   int tile_width, int tile_height, int32_t* tiles_per_gauss,
-                                  int32_t* isect_offsets, int64_t* meta_dev, void* workspace,
+                                  int32_t* isect_offsets, int64_t* meta_dev, void* count_workspace,
                                   size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (!meta_dev) return SC_EINVAL;
@@ -462,25 +539,39 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
         if (nb > 0 && isect_offsets) SC_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)nb * 4, s));
         return (int)hipMemsetAsync(meta_dev, 0, 2 * sizeof(int64_t), s);
     }
-    if (!means2d || !radii || !tiles_per_gauss || !isect_offsets || !workspace) return SC_EINVAL;
-    if (ws_bytes < 2 * bin_counts_bytes(nb)) return SC_EWORKSPACE;
-    unsigned* counts = (unsigned*)workspace;
-    SC_HIP(hipMemsetAsync(counts, 0, (size_t)nb * 4, s));
+    if (!means2d || !radii || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
+    const BinCountLayout L = bin_count_layout(CN, nb);
+    if (ws_bytes < L.total) return SC_EWORKSPACE;
+    unsigned char* ws = (unsigned char*)count_workspace;
+    unsigned* counts = (unsigned*)(ws + L.counts);
+    unsigned* ccounts = (unsigned*)(ws + L.ccounts);
+    unsigned* ccursor = (unsigned*)(ws + L.ccursor);
+    int32_t* cstart = (int32_t*)(ws + L.cstart);
+    int64_t* cmeta = (int64_t*)(ws + L.cmeta);
+    int32_t* perm = (int32_t*)(ws + L.perm);
+    SC_HIP(hipMemsetAsync(ws, 0, 3 * bin_counts_bytes(nb), s));        // counts, ccounts, ccursor
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 4, s, means2d, radii, CN, N,
-                       (float)tile_size, tile_width, tile_height, nb, tiles_per_gauss, counts);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, CN, N,
+                       (float)tile_size, tile_width, tile_height, nb, tiles_per_gauss, counts, ccounts);
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)counts, nb, isect_offsets,
                        meta_dev);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)ccounts, nb, cstart, cmeta);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s,
+                       (const int32_t*)tiles_per_gauss, means2d, radii, CN, N, (float)tile_size, tile_width,
+                       tile_height, nb, (const int32_t*)cstart, ccursor, perm);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
 
 extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C,
                                  int N, int tile_size, int tile_width, int tile_height,
-                                 const int32_t* isect_offsets, const int64_t* meta_dev, int64_t capacity,
-                                 int64_t tile_capacity, int64_t* isect_ids, int32_t* flatten_ids,
-                                 void* workspace, size_t ws_bytes, sc_stream_t stream) {
+                                 const int32_t* isect_offsets, const int64_t* meta_dev,
+                                 const void* count_workspace, int64_t capacity, int64_t tile_capacity,
+                                 int64_t* isect_ids, int32_t* flatten_ids, void* workspace,
+                                 size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0 || capacity < 0 ||
         tile_capacity < 0)
         return SC_EINVAL;
@@ -489,23 +580,28 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     if (nb64 > BIN_MAX_BUCKETS || CN > 0x7fffffffLL || capacity > 0x7fffffffLL) return SC_EUNSUPPORTED;
     if (capacity == 0 || CN == 0) return SC_OK;
     const int nb = (int)nb64;
-    // LDS capacity of one tile-sort workgroup: two 8-byte copies of the bucket must fit 144 KiB
+    // LDS of one tile-sort workgroup: 16 B per record must fit ~150 KiB
     if (tile_capacity > 9216) return SC_EUNSUPPORTED;
     int cap = (int)((tile_capacity + 255) / 256 * 256);
     if (cap < 256) cap = 256;
-    if (!means2d || !radii || !depths || !isect_offsets || !meta_dev || !flatten_ids || !workspace)
+    if (!means2d || !radii || !depths || !isect_offsets || !meta_dev || !count_workspace || !flatten_ids ||
+        !workspace)
         return SC_EINVAL;
     if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, capacity)) return SC_EWORKSPACE;
     hipStream_t s = sc_s(stream);
+    const BinCountLayout L = bin_count_layout(CN, nb);
+    const unsigned char* cws = (const unsigned char*)count_workspace;
+    const int64_t* cmeta = (const int64_t*)(cws + L.cmeta);
+    const int32_t* perm = (const int32_t*)(cws + L.perm);
     unsigned char* ws = (unsigned char*)workspace;
-    unsigned* cursor = (unsigned*)(ws + bin_counts_bytes(nb));
-    unsigned char* needs_radix = ws + 2 * bin_counts_bytes(nb);
-    uint2* bucket = (uint2*)(ws + 3 * bin_counts_bytes(nb));
-    SC_HIP(hipMemsetAsync(cursor, 0, 2 * bin_counts_bytes(nb), s));   // cursor + needs_radix flags
+    unsigned* cursor = (unsigned*)ws;
+    unsigned char* needs_radix = ws + bin_counts_bytes(nb);
+    uint2* bucket = (uint2*)(ws + 2 * bin_counts_bytes(nb));
+    SC_HIP(hipMemsetAsync(ws, 0, 2 * bin_counts_bytes(nb), s));   // cursor + needs_radix flags
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, depths,
-                       CN, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, meta_dev, capacity,
-                       (int64_t)cap, cursor, bucket, g_sc_debug[0]);
+                       perm, cmeta, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, meta_dev,
+                       capacity, (int64_t)cap, cursor, bucket, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
     const int tiles_per_cam = tile_width * tile_height;
     const int tile_bits = sc_bits_for(tiles_per_cam);

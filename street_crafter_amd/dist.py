@@ -22,8 +22,21 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
 
 
 def to_uint8_frame(rgb_chw: torch.Tensor) -> torch.Tensor:
-    """[3,H,W] float in [0,1] -> [H,W,3] uint8 (what the reference's visualizer writes to disk)."""
-    return (rgb_chw.detach().clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous()
+    """[3,H,W] float -> [H,W,3] uint8 = clamp(.,0,1)*255 rounded half up (what the reference's
+    visualizer writes to disk).  On a HIP device this is ONE fused kernel (sc_frame_to_u8) when
+    the tensor is the permuted view of an [H,W,C>=3] image, as the renderer returns it."""
+    x = rgb_chw.detach()
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] == 3:
+        hwc = x.permute(1, 2, 0)                      # [H,W,3] view
+        H, W = hwc.shape[0], hwc.shape[1]
+        if hwc.stride(2) == 1 and hwc.stride(1) >= 3 and hwc.stride(0) == W * hwc.stride(1):
+            from . import _lib
+            out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+            _lib.check(_lib.load().sc_frame_to_u8(hwc.data_ptr(), H * W, hwc.stride(1), out.data_ptr(),
+                                                  torch.cuda.current_stream(x.device).cuda_stream),
+                       "sc_frame_to_u8")
+            return out
+    return (x.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous()
 
 
 class FrameGatherer:

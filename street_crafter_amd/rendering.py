@@ -217,7 +217,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
     meta_dev = torch.empty(2, dtype=torch.int64, device=dev)
-    ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, 0), dev)
+    ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev), _p(ws0),
                                 ws0.numel(), st)
@@ -234,7 +234,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         fids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, capacity), dev)
         r = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
-                                  int(tile_height), _p(offsets), _p(meta_dev), capacity, tile_capacity,
+                                  int(tile_height), _p(offsets), _p(meta_dev), _p(ws0), capacity, tile_capacity,
                                   _p(ids), _p(fids), _p(ws), ws.numel(), st)
         return r, ids, fids
 

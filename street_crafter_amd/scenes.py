@@ -42,16 +42,17 @@ class Camera:
     height: int
     znear: float = 0.001      # street_gaussian/utils/camera_utils.py:47-48
     zfar: float = 1000.0
+    camera_center: torch.Tensor = None   # f32[3], precomputed like the reference's Camera.camera_center
 
-    @property
-    def camera_center(self):
-        R = self.viewmat[:3, :3].double()
-        t = self.viewmat[:3, 3].double()
-        return (-(R.T @ t)).float()
+    def __post_init__(self):
+        if self.camera_center is None:
+            R = self.viewmat[:3, :3].double().cpu()
+            t = self.viewmat[:3, 3].double().cpu()
+            self.camera_center = (-(R.T @ t)).float().to(self.viewmat.device)
 
     def to(self, device):
         return Camera(self.viewmat.to(device), self.K.to(device), self.width, self.height,
-                      self.znear, self.zfar)
+                      self.znear, self.zfar, self.camera_center.to(device))
 
 
 def make_camera(width=1920, height=1280, fx=2050.0, fy=2050.0, yaw=0.0, shift=(0.0, 0.0, 0.0)):
