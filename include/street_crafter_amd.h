@@ -171,7 +171,8 @@ int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
- *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled (default)
+ *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,
+ *                     2 = culled + software-pipelined gathers + XCD-aware tile map (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)
  * Returns the previous value, or SC_EINVAL for an unknown key. */

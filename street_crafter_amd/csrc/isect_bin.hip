@@ -402,6 +402,9 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
 // equal depths) is flagged and left to tile_sort_kernel.
 constexpr int BS_MAX_OCC = 48;
 
+// E > 0: every thread keeps its <= E records in registers (one global read per record, tiles up to
+// 256*E records); E == 0: records are re-read from global/L2 in each of the three passes.
+template <int E>
 __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
     const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int cap,
@@ -427,11 +430,26 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     const int per_thread = nbk / TS_THREADS;
     for (int i = t; i <= nbk; i += TS_THREADS) boff[i] = 0;
 
+    constexpr int EE = E > 0 ? E : 1;
+    uint2 rec[EE];
     unsigned lo = 0xffffffffu, hi = 0u;
-    for (int i = t; i < n; i += TS_THREADS) {
-        const unsigned d = bucket[s + i].x;
-        lo = min(lo, d);
-        hi = max(hi, d);
+    if constexpr (E > 0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int i = t + k * TS_THREADS;
+            rec[k] = make_uint2(0u, 0u);
+            if (i < n) {
+                rec[k] = bucket[s + i];
+                lo = min(lo, rec[k].x);
+                hi = max(hi, rec[k].x);
+            }
+        }
+    } else {
+        for (int i = t; i < n; i += TS_THREADS) {
+            const unsigned d = bucket[s + i].x;
+            lo = min(lo, d);
+            hi = max(hi, d);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -449,7 +467,13 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     };
 
     // histogram
-    for (int i = t; i < n; i += TS_THREADS) atomicAdd(&boff[sub_bucket(bucket[s + i].x)], 1u);
+    if constexpr (E > 0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if (t + k * TS_THREADS < n) atomicAdd(&boff[sub_bucket(rec[k].x)], 1u);
+    } else {
+        for (int i = t; i < n; i += TS_THREADS) atomicAdd(&boff[sub_bucket(bucket[s + i].x)], 1u);
+    }
     __syncthreads();
     // exclusive scan over nbk counters: thread t owns per_thread consecutive counters
     unsigned sum = 0, occ = 0;
@@ -479,10 +503,20 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     }
     __syncthreads();
     // scatter: after this pass boff[j] is the END of sub-bucket j (== start of j+1)
-    for (int i = t; i < n; i += TS_THREADS) {
-        const uint2 r = bucket[s + i];
-        const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
-        B[slot] = ((unsigned long long)r.x << 32) | r.y;
+    if constexpr (E > 0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            if (t + k * TS_THREADS < n) {
+                const unsigned slot = atomicAdd(&boff[sub_bucket(rec[k].x)], 1u);
+                B[slot] = ((unsigned long long)rec[k].x << 32) | rec[k].y;
+            }
+        }
+    } else {
+        for (int i = t; i < n; i += TS_THREADS) {
+            const uint2 r = bucket[s + i];
+            const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
+            B[slot] = ((unsigned long long)r.x << 32) | r.y;
+        }
     }
     __syncthreads();
     // rank inside the sub-bucket by (depth bits, flat id) and write the final records
@@ -610,14 +644,22 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    152 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel,
+        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel<0>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel<12>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
     // common path: interpolation sort; it flags the (rare) tiles it leaves to the radix kernel
-    hipLaunchKernelGGL(tile_bucket_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16 + 16, s,
-                       (const uint2*)bucket, isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, cap,
-                       needs_radix, isect_ids, flatten_ids);
+#define SC_LAUNCH_BS(EV)                                                                                      \
+    hipLaunchKernelGGL(tile_bucket_sort_kernel<EV>, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16 + 16, s,          \
+                       (const uint2*)bucket, isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, cap, \
+                       needs_radix, isect_ids, flatten_ids)
+    if (cap <= 4 * TS_THREADS) SC_LAUNCH_BS(4);
+    else if (cap <= 8 * TS_THREADS) SC_LAUNCH_BS(8);
+    else if (cap <= 12 * TS_THREADS) SC_LAUNCH_BS(12);
+    else SC_LAUNCH_BS(0);
+#undef SC_LAUNCH_BS
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(tile_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16, s, (const uint2*)bucket,
                        isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, id_bits, cap,

@@ -2,9 +2,9 @@
 // Replaces gsplat.rendering.rasterize_to_pixels as called at
 // street_gaussian/models/street_gaussian_renderer.py:267-280 (semantics: SURVEY.md A.5).
 //
-// Two variants, selectable at run time with sc_set_option("raster_fwd", v) for A/B runs:
+// Three variants, selectable at run time with sc_set_option("raster_fwd", v) for A/B runs:
 //   0  reference-shaped: one lane per pixel, every lane evaluates every splat of the tile.
-//   1  culled (default, tile_size 16): while a batch is staged into LDS each staging lane tests
+//   1  culled (tile_size 16): while a batch is staged into LDS each staging lane tests
 //      its splat's alpha >= 1/255 ellipse against the tile rectangle (an exact, conservative
 //      test) and the batch is compacted with a wave ballot + prefix sum, so the per-pixel loop
 //      only walks splats that can touch the tile.  Splats that are dropped would have been
@@ -14,7 +14,7 @@
 // to ~1e-6 relative, not bitwise (tolerance stated in tests/test_gpu_parity.py).
 #include "raster_common.h"
 
-int g_sc_raster_fwd_variant = 1;
+int g_sc_raster_fwd_variant = 2;
 
 namespace {
 
@@ -288,6 +288,380 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// variant 2: variant 1's algorithm, restructured for latency:
+//   * 1-D grid with an XCD-aware tile map: blocks b, b+8, b+16.. share an XCD (and its 4 MiB L2),
+//     so each XCD gets one contiguous band of tile rows and the splat parameters its tiles gather
+//     stay L2-resident (speed only: any placement is correct);
+//   * the gathers are software-pipelined through registers: while batch b is blended, the
+//     parameters of batch b+1 and the ids of batch b+2 are already in flight;
+//   * the blend loop is predicated (no per-lane continue/break), prefetches the next LDS record,
+//     and leaves as soon as every lane of the WAVE is done.
+// Same arithmetic (raster_common.h) -> bit-identical output to variants 0 and 1.
+// ------------------------------------------------------------------------------------------
+template <int CDIM>
+__global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
+    int width, int height, int tile_width, int tile_height, int total_tiles,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas,
+    int32_t* __restrict__ last_ids, int dbg) {
+    constexpr int B = 256;
+    __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
+    __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
+    __shared__ float4 col_s[B + 1];       // colour channels
+    __shared__ int wave_cnt_s[4];
+
+    // XCD-aware bijective remap of the linear block id (guide T1)
+    int tflat;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_per_cam = tile_width * tile_height;
+    const int cam = tflat / tiles_per_cam;
+    const int tile_id = tflat - cam * tiles_per_cam;
+    const int tyi = tile_id / tile_width, txi = tile_id - tyi * tile_width;
+    const int tr = threadIdx.x;
+    const int lane = tr & 63, wave = tr >> 6;
+    const int lx = tr & 15, ly = tr >> 4;
+    const int px_i = txi * 16 + lx, py_i = tyi * 16 + ly;
+    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
+    const bool inside = (px_i < width) && (py_i < height);
+    const int64_t pix = ((int64_t)cam * height + py_i) * width + px_i;
+
+    if (tile_masks && !tile_masks[tflat]) {
+        if (inside) {
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d)
+                render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
+            render_alphas[pix] = 0.f;
+            last_ids[pix] = 0;
+        }
+        return;
+    }
+    const int range_start = isect_offsets[tflat];
+    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    const int num_batches = (range_end - range_start + B - 1) / B;
+
+    const float rx0 = (float)(txi * 16) + 0.5f;
+    const float ry0 = (float)(tyi * 16) + 0.5f;
+    const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
+    const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
+
+    float T = 1.0f;
+    int cur_idx = 0;
+    bool done = !inside;
+    float pix_out[CDIM];
+#pragma unroll
+    for (int d = 0; d < CDIM; ++d) pix_out[d] = 0.f;
+
+    // ---- pipeline prologue: parameters of batch 0, id of batch 1 ----------------------------------
+    float2 p_xy = make_float2(0.f, 0.f);
+    float p_a = 0.f, p_b = 0.f, p_c = 0.f, p_op = 0.f;
+    float4 p_col = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool p_live = false;
+    int g_next = -1;
+    {
+        const int idx0 = range_start + tr;
+        if (idx0 < range_end) {
+            const int g = flatten_ids[idx0];
+            p_xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+            const float* cn = conics + (int64_t)g * 3;
+            p_a = cn[0]; p_b = cn[1]; p_c = cn[2];
+            p_op = opacities[g];
+            const float* c = colors + (int64_t)g * CDIM;
+            p_col = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+            p_live = true;
+        }
+        const int idx1 = idx0 + B;
+        if (idx1 < range_end) g_next = flatten_ids[idx1];
+    }
+
+    for (int b = 0; b < num_batches; ++b) {
+        if (__syncthreads_count(done) >= B) break;
+        const int batch_start = range_start + B * b;
+        // ---- cull + compact batch b (its parameters are in registers) -----------------------------
+        bool keep = false;
+        if (p_live)
+            keep = !splat_misses_rect(p_a, p_b, p_c, p_op, rx0 - p_xy.x, rx1 - p_xy.x, ry0 - p_xy.y, ry1 - p_xy.y);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wave_cnt_s[wave] = __popcll(m);
+        __syncthreads();
+        int base = 0, bsz = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int c = wave_cnt_s[w];
+            if (w < wave) base += c;
+            bsz += c;
+        }
+        if (keep) {
+            const int slot = base + __popcll(m & sc_lanemask_lt());
+            xyoa_s[slot] = make_float4(p_xy.x, p_xy.y, p_op, p_a);
+            bck_s[slot] = make_float4(p_b, p_c, __int_as_float(batch_start + tr), 0.f);
+            col_s[slot] = p_col;
+        }
+        __syncthreads();
+        // ---- put batch b+1's parameters and batch b+2's ids in flight ------------------------------
+        {
+            p_live = g_next >= 0;
+            if (p_live) {
+                const int g = g_next;
+                p_xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+                const float* cn = conics + (int64_t)g * 3;
+                p_a = cn[0]; p_b = cn[1]; p_c = cn[2];
+                p_op = opacities[g];
+                const float* c = colors + (int64_t)g * CDIM;
+                p_col = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+            }
+            const int idx2 = batch_start + 2 * B + tr;
+            g_next = (idx2 < range_end) ? flatten_ids[idx2] : -1;
+        }
+        // ---- blend batch b ---------------------------------------------------------------------------
+        if (dbg & 1) bsz = 0;
+        if (bsz > 0) {
+            float4 a = xyoa_s[0], bc = bck_s[0], c = col_s[0];
+            for (int t = 0; t < bsz; ++t) {
+                const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
+                const float dx = a.x - px, dy = a.y - py;
+                const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
+                const float alpha = sc_alpha(a.z, sc_vis(sigma));
+                const bool valid = !done && !(sigma < 0.f) && !(alpha < SC_ALPHA_MIN);
+                const float next_T = sc_next_T(T, alpha);
+                const bool term = valid && (next_T <= SC_T_EPS);
+                done = done || term;
+                if (valid && !term) {
+                    const float vis = __fmul_rn(alpha, T);
+                    pix_out[0] = __fmaf_rn(c.x, vis, pix_out[0]);
+                    pix_out[1] = __fmaf_rn(c.y, vis, pix_out[1]);
+                    pix_out[2] = __fmaf_rn(c.z, vis, pix_out[2]);
+                    if (CDIM > 3) pix_out[3] = __fmaf_rn(c.w, vis, pix_out[3]);
+                    cur_idx = __float_as_int(bc.z);
+                    T = next_T;
+                }
+                if (__all(done)) break;
+                a = an; bc = bcn; c = cn;
+            }
+        }
+    }
+    if (inside) {
+        render_alphas[pix] = 1.0f - T;
+        if (CDIM == 4) {
+            float4 o = make_float4(pix_out[0], pix_out[1], pix_out[2], pix_out[3]);
+            if (backgrounds) {
+                o.x += T * backgrounds[cam * 4 + 0]; o.y += T * backgrounds[cam * 4 + 1];
+                o.z += T * backgrounds[cam * 4 + 2]; o.w += T * backgrounds[cam * 4 + 3];
+            }
+            *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
+        } else {
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d)
+                render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
+        }
+        last_ids[pix] = cur_idx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// variant 3: ONE WAVE PER TILE, four pixels per lane (lane l owns pixels x = 4*(l&3)..+3 of row
+// l>>2 of the 16x16 tile).  Measured on variant 2 the blend loop was co-bound by the LDS
+// broadcast reads of the splat record (3 x ds_read_b128 per splat per wave, 4 waves per tile)
+// and by VALU; with one wave per tile each record is read once per tile instead of four times,
+// dy-dependent terms are shared by the lane's four pixels, there is no workgroup barrier at all
+// (the workgroup IS the wave), the whole-tile early exit is a single wave vote, and up to 32
+// tiles are resident per CU to hide the gather latency.  The lane stores its four pixels as
+// 64 contiguous bytes.  Same pinned arithmetic -> bit-identical to variants 0-2.
+// ------------------------------------------------------------------------------------------
+template <int CDIM>
+__global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
+    int width, int height, int tile_width, int tile_height, int total_tiles,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas,
+    int32_t* __restrict__ last_ids, int dbg) {
+    constexpr int SB = 2;                 // splats staged per lane per batch
+    constexpr int B = 64 * SB;            // batch size
+    __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
+    __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
+    __shared__ float4 col_s[B + 1];       // colour channels
+
+    int tflat;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_per_cam = tile_width * tile_height;
+    const int cam = tflat / tiles_per_cam;
+    const int tile_id = tflat - cam * tiles_per_cam;
+    const int tyi = tile_id / tile_width, txi = tile_id - tyi * tile_width;
+    const int lane = threadIdx.x;
+    const int px0_i = txi * 16 + 4 * (lane & 3), py_i = tyi * 16 + (lane >> 2);
+    const float py = (float)py_i + 0.5f;
+    float pxf[4];
+    bool inside[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        pxf[k] = (float)(px0_i + k) + 0.5f;
+        inside[k] = (px0_i + k < width) && (py_i < height);
+    }
+    const int64_t pix0 = ((int64_t)cam * height + py_i) * width + px0_i;
+
+    if (tile_masks && !tile_masks[tflat]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (inside[k]) {
+#pragma unroll
+                for (int d = 0; d < CDIM; ++d)
+                    render_colors[(pix0 + k) * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
+                render_alphas[pix0 + k] = 0.f;
+                last_ids[pix0 + k] = 0;
+            }
+        }
+        return;
+    }
+    const int range_start = isect_offsets[tflat];
+    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    const int num_batches = (range_end - range_start + B - 1) / B;
+
+    const float rx0 = (float)(txi * 16) + 0.5f;
+    const float ry0 = (float)(tyi * 16) + 0.5f;
+    const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
+    const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
+
+    float T[4] = {1.f, 1.f, 1.f, 1.f};
+    int cur[4] = {0, 0, 0, 0};
+    bool done[4];
+    float acc[4][CDIM];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        done[k] = !inside[k];
+#pragma unroll
+        for (int d = 0; d < CDIM; ++d) acc[k][d] = 0.f;
+    }
+
+    // register-staged pipeline: parameters of batch b, ids of batch b+1
+    float2 p_xy[SB];
+    float p_a[SB], p_b[SB], p_c[SB], p_op[SB];
+    float4 p_col[SB];
+    bool p_live[SB];
+    int g_next[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        const int idx0 = range_start + j * 64 + lane;
+        p_live[j] = idx0 < range_end;
+        p_xy[j] = make_float2(0.f, 0.f);
+        p_a[j] = p_b[j] = p_c[j] = p_op[j] = 0.f;
+        p_col[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p_live[j]) {
+            const int g = flatten_ids[idx0];
+            p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+            const float* cn = conics + (int64_t)g * 3;
+            p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
+            p_op[j] = opacities[g];
+            const float* c = colors + (int64_t)g * CDIM;
+            p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+        }
+        const int idx1 = idx0 + B;
+        g_next[j] = (idx1 < range_end) ? flatten_ids[idx1] : -1;
+    }
+
+    for (int b = 0; b < num_batches; ++b) {
+        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        const int batch_start = range_start + B * b;
+        // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
+        int bsz = 0;
+        __syncthreads();   // single-wave workgroup: orders the previous batch's LDS reads vs these writes
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            bool keep = false;
+            if (p_live[j])
+                keep = !splat_misses_rect(p_a[j], p_b[j], p_c[j], p_op[j], rx0 - p_xy[j].x, rx1 - p_xy[j].x,
+                                          ry0 - p_xy[j].y, ry1 - p_xy[j].y);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int slot = bsz + __popcll(m & sc_lanemask_lt());
+                xyoa_s[slot] = make_float4(p_xy[j].x, p_xy[j].y, p_op[j], p_a[j]);
+                bck_s[slot] = make_float4(p_b[j], p_c[j], __int_as_float(batch_start + j * 64 + lane), 0.f);
+                col_s[slot] = p_col[j];
+            }
+            bsz += __popcll(m);
+        }
+        __syncthreads();
+        // ---- next batch's parameters and the ids after that go in flight ---------------------------
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            p_live[j] = g_next[j] >= 0;
+            if (p_live[j]) {
+                const int g = g_next[j];
+                p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+                const float* cn = conics + (int64_t)g * 3;
+                p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
+                p_op[j] = opacities[g];
+                const float* c = colors + (int64_t)g * CDIM;
+                p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+            }
+            const int idx2 = batch_start + 2 * B + j * 64 + lane;
+            g_next[j] = (idx2 < range_end) ? flatten_ids[idx2] : -1;
+        }
+        // ---- blend ---------------------------------------------------------------------------------
+        if (dbg & 1) bsz = 0;
+        if (bsz > 0) {
+            float4 a = xyoa_s[0], bc = bck_s[0], c = col_s[0];
+            for (int t = 0; t < bsz; ++t) {
+                const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
+                const float dy = a.y - py;
+                const int sidx = __float_as_int(bc.z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = a.x - pxf[k];
+                    const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
+                    const float alpha = sc_alpha(a.z, sc_vis(sigma));
+                    const bool valid = !done[k] && !(sigma < 0.f) && !(alpha < SC_ALPHA_MIN);
+                    const float next_T = sc_next_T(T[k], alpha);
+                    const bool term = valid && (next_T <= SC_T_EPS);
+                    done[k] = done[k] || term;
+                    const bool blend = valid && !term;
+                    const float vis = blend ? __fmul_rn(alpha, T[k]) : 0.f;
+                    // adding c*0 leaves the sums bit-identical to skipping (sums are never -0)
+                    acc[k][0] = __fmaf_rn(c.x, vis, acc[k][0]);
+                    acc[k][1] = __fmaf_rn(c.y, vis, acc[k][1]);
+                    acc[k][2] = __fmaf_rn(c.z, vis, acc[k][2]);
+                    if (CDIM > 3) acc[k][3] = __fmaf_rn(c.w, vis, acc[k][3]);
+                    cur[k] = blend ? sidx : cur[k];
+                    T[k] = blend ? next_T : T[k];
+                }
+                if (__all(done[0] && done[1] && done[2] && done[3])) break;
+                a = an; bc = bcn; c = cn;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!inside[k]) continue;
+        const int64_t pix = pix0 + k;
+        render_alphas[pix] = 1.0f - T[k];
+        if (CDIM == 4) {
+            float4 o = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+            if (backgrounds) {
+                o.x += T[k] * backgrounds[cam * 4 + 0]; o.y += T[k] * backgrounds[cam * 4 + 1];
+                o.z += T[k] * backgrounds[cam * 4 + 2]; o.w += T[k] * backgrounds[cam * 4 + 3];
+            }
+            *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
+        } else {
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d)
+                render_colors[pix * CDIM + d] = backgrounds ? acc[k][d] + T[k] * backgrounds[cam * CDIM + d] : acc[k][d];
+        }
+        last_ids[pix] = cur[k];
+    }
+}
+
 }  // namespace
 
 extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
@@ -307,7 +681,37 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     dim3 grid(tile_width, tile_height, C);
     const int variant = g_sc_raster_fwd_variant;
-    if (variant == 1 && tile_size == 16 && (D == 3 || D == 4)) {
+    if (variant == 3 && tile_size == 16 && (D == 3 || D == 4)) {
+        const int total_tiles = C * tile_width * tile_height;
+        if (D == 4)
+            hipLaunchKernelGGL(raster_fwd_wave_kernel<4>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,
+                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
+                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
+        else
+            hipLaunchKernelGGL(raster_fwd_wave_kernel<3>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,
+                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
+                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
+        SC_LAUNCH_CHECK();
+        return SC_OK;
+    }
+    if (variant == 2 && tile_size == 16 && (D == 3 || D == 4)) {
+        const int total_tiles = C * tile_width * tile_height;
+        if (D == 4)
+            hipLaunchKernelGGL(raster_fwd_v2_kernel<4>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
+                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
+                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
+        else
+            hipLaunchKernelGGL(raster_fwd_v2_kernel<3>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
+                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
+                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
+        SC_LAUNCH_CHECK();
+        return SC_OK;
+    }
+    if (variant >= 1 && tile_size == 16 && (D == 3 || D == 4)) {
         if (D == 4)
             hipLaunchKernelGGL(raster_fwd_cull_kernel<4>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
                                colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,

@@ -29,6 +29,10 @@ CONFIGS = [
     ("raster: no blend loop", {"debug1": 1}),
     ("isect radix route", {"isect": "radix"}),
     ("raster variant 0", {"raster_fwd": 0}),
+    ("raster variant 1", {"raster_fwd": 1}),
+    ("raster variant 2", {"raster_fwd": 2}),
+    ("raster variant 3", {"raster_fwd": 3}),
+    ("raster variant 3, no blend", {"raster_fwd": 3, "debug1": 1}),
 ]
 
 
