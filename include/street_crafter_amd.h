@@ -144,7 +144,11 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      int tile_width, int tile_height,
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                      float* render_colors, float* render_alphas, int32_t* last_ids,
-                     sc_stream_t stream);
+                     void* workspace /* nullable: sc_rasterize_workspace_bytes(C,N,D) bytes */,
+                     size_t ws_bytes, sc_stream_t stream);
+/* scratch for the packed-record fast path (64 B per (camera, splat)); without it the kernels gather
+ * from the four parameter arrays directly */
+size_t sc_rasterize_workspace_bytes(int C, int N, int D);
 /* Gradient outputs must be ZERO-FILLED by the caller (the kernel accumulates with atomics).
  * v_means2d_abs nullable (absgrad). */
 int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
@@ -172,7 +176,8 @@ int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,
- *                     2 = culled + software-pipelined gathers + XCD-aware tile map (default)
+ *                     2 = culled + software-pipelined gathers + XCD-aware tile map,
+ *                     3 = one wave per tile, 4 pixels per lane, 4 = 3 + packed 64-B records (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)
  * Returns the previous value, or SC_EINVAL for an unknown key. */

@@ -14,7 +14,7 @@
 // to ~1e-6 relative, not bitwise (tolerance stated in tests/test_gpu_parity.py).
 #include "raster_common.h"
 
-int g_sc_raster_fwd_variant = 2;
+int g_sc_raster_fwd_variant = 4;
 
 namespace {
 
@@ -475,10 +475,13 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
 // tiles are resident per CU to hide the gather latency.  The lane stores its four pixels as
 // 64 contiguous bytes.  Same pinned arithmetic -> bit-identical to variants 0-2.
 // ------------------------------------------------------------------------------------------
-template <int CDIM>
+// PACKED: the splat parameters come from 64-byte records written by raster_pack_kernel (one
+// 64-B transaction per staged splat instead of four or five 4..16-B gathers from four arrays).
+template <int CDIM, bool PACKED>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float4* __restrict__ recs,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
@@ -551,15 +554,14 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     float4 p_col[SB];
     bool p_live[SB];
     int g_next[SB];
-#pragma unroll
-    for (int j = 0; j < SB; ++j) {
-        const int idx0 = range_start + j * 64 + lane;
-        p_live[j] = idx0 < range_end;
-        p_xy[j] = make_float2(0.f, 0.f);
-        p_a[j] = p_b[j] = p_c[j] = p_op[j] = 0.f;
-        p_col[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p_live[j]) {
-            const int g = flatten_ids[idx0];
+    auto load_splat = [&](int g, int j) {
+        if constexpr (PACKED) {
+            const float4* r = recs + (int64_t)g * 4;
+            const float4 r0 = r[0], r1 = r[1];
+            p_col[j] = r[2];
+            p_xy[j] = make_float2(r0.x, r0.y);
+            p_op[j] = r0.z; p_a[j] = r0.w; p_b[j] = r1.x; p_c[j] = r1.y;
+        } else {
             p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
             const float* cn = conics + (int64_t)g * 3;
             p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
@@ -567,6 +569,15 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             const float* c = colors + (int64_t)g * CDIM;
             p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
         }
+    };
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+        const int idx0 = range_start + j * 64 + lane;
+        p_live[j] = idx0 < range_end;
+        p_xy[j] = make_float2(0.f, 0.f);
+        p_a[j] = p_b[j] = p_c[j] = p_op[j] = 0.f;
+        p_col[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p_live[j]) load_splat(flatten_ids[idx0], j);
         const int idx1 = idx0 + B;
         g_next[j] = (idx1 < range_end) ? flatten_ids[idx1] : -1;
     }
@@ -597,15 +608,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             p_live[j] = g_next[j] >= 0;
-            if (p_live[j]) {
-                const int g = g_next[j];
-                p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-                const float* cn = conics + (int64_t)g * 3;
-                p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
-                p_op[j] = opacities[g];
-                const float* c = colors + (int64_t)g * CDIM;
-                p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-            }
+            if (p_live[j]) load_splat(g_next[j], j);
             const int idx2 = batch_start + 2 * B + j * 64 + lane;
             g_next[j] = (idx2 < range_end) ? flatten_ids[idx2] : -1;
         }
@@ -662,7 +665,29 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     }
 }
 
+// 64-byte record per (camera, splat): [mx my op a | b c - - | colour x4 | pad]
+template <int CDIM>
+__global__ __launch_bounds__(256) void raster_pack_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities, int64_t CN,
+    float4* __restrict__ recs) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= CN) return;
+    const float2 xy = *reinterpret_cast<const float2*>(means2d + g * 2);
+    const float* cn = conics + g * 3;
+    const float* c = colors + g * CDIM;
+    float4* r = recs + g * 4;
+    r[0] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
+    r[1] = make_float4(cn[1], cn[2], 0.f, 0.f);
+    r[2] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
+}
+
 }  // namespace
+
+extern "C" size_t sc_rasterize_workspace_bytes(int C, int N, int D) {
+    if (C <= 0 || N <= 0 || (D != 3 && D != 4)) return 256;
+    return sc_align_up((size_t)C * N * 64, 256);
+}
 
 extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
                                 const float* opacities, const float* backgrounds,
@@ -670,7 +695,7 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
                                 int tile_size, int tile_width, int tile_height,
                                 const int32_t* isect_offsets, const int32_t* flatten_ids,
                                 int64_t n_isects, float* render_colors, float* render_alphas,
-                                int32_t* last_ids, sc_stream_t stream) {
+                                int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
@@ -681,18 +706,34 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     dim3 grid(tile_width, tile_height, C);
     const int variant = g_sc_raster_fwd_variant;
-    if (variant == 3 && tile_size == 16 && (D == 3 || D == 4)) {
+    if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         const int total_tiles = C * tile_width * tile_height;
-        if (D == 4)
-            hipLaunchKernelGGL(raster_fwd_wave_kernel<4>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
-                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
-                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
-        else
-            hipLaunchKernelGGL(raster_fwd_wave_kernel<3>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
-                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
-                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
+        const int64_t CN = (int64_t)C * N;
+        // variant 4: pack the parameters into 64-B records first (needs the workspace)
+        const bool packed = variant == 4 && workspace && ws_bytes >= sc_rasterize_workspace_bytes(C, N, D) &&
+                            n_isects > 0;
+        float4* recs = packed ? (float4*)workspace : nullptr;
+#define SC_LAUNCH_WAVE(CD, PK)                                                                                  \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
+                       conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, N, width, height,  \
+                       tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,            \
+                       render_colors, render_alphas, last_ids, g_sc_debug[1])
+        if (packed) {
+            const unsigned pg = (unsigned)((CN + 255) / 256);
+            if (D == 4) {
+                hipLaunchKernelGGL(raster_pack_kernel<4>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
+                                   colors, opacities, CN, recs);
+                SC_LAUNCH_WAVE(4, true);
+            } else {
+                hipLaunchKernelGGL(raster_pack_kernel<3>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
+                                   colors, opacities, CN, recs);
+                SC_LAUNCH_WAVE(3, true);
+            }
+        } else {
+            if (D == 4) SC_LAUNCH_WAVE(4, false);
+            else SC_LAUNCH_WAVE(3, false);
+        }
+#undef SC_LAUNCH_WAVE
         SC_LAUNCH_CHECK();
         return SC_OK;
     }

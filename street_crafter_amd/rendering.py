@@ -343,10 +343,12 @@ class _Rasterize(torch.autograd.Function):
         render_colors = torch.empty((C, height, width, D), dtype=torch.float32, device=dev)
         render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
         last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev)
+        ws = _ws(lib.sc_rasterize_workspace_bytes(C, N, D), dev)
         _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
                                         _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
                                         _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-                                        _p(render_colors), _p(render_alphas), _p(last_ids), _stream(means2d)),
+                                        _p(render_colors), _p(render_alphas), _p(last_ids), _p(ws), ws.numel(),
+                                        _stream(means2d)),
                    "sc_rasterize_fwd")
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,

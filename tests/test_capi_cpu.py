@@ -59,9 +59,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_sh_fwd(5, None, None, None, 4, 36, None, None) == -1              # degree > 4
     assert lib.sc_sh_fwd(3, None, None, None, 4, 9, None, None) == -1               # K < 16
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 33, 64, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None) == -1        # D > 32
+                                None, None, 0, None, None, None, None, 0, None) == -1        # D > 32
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 3, 65, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None) == -1        # tiles too few
+                                None, None, 0, None, None, None, None, 0, None) == -1        # tiles too few
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 10, 65, None, 0, None) == -1
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 1, 40, None, 0, None) == 0   # n<=1 no-op
     assert lib.sc_knn3_mean_dist2(None, 0, None, None, 0, None) == 0

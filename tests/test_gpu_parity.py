@@ -213,7 +213,7 @@ def test_sh_forward_bit_exact_and_reference(ops, golden_dir, deg):
     assert float(got[0][~torch.from_numpy(masks).to(DEV)].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_rasterize_golden(ops, golden_dir, variant):
     from street_crafter_amd import _lib
     g = _load(golden_dir, "pipeline_small.npz")
@@ -240,7 +240,7 @@ def _pipeline_inputs(n, cam, seed, **kw):
     return sc, exp
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("w,h", [(256, 160), (200, 120)])
 def test_full_pipeline_vs_oracle(ops, variant, w, h):
     """The caller's whole sequence (pipeline.render_gaussians == render_kernel_gsplat) vs the oracle:
@@ -492,7 +492,7 @@ def test_full_size_properties_1m(ops):
         _lib.set_option("raster_fwd", prev)
     assert torch.equal(out0["_render_colors"], out["_render_colors"])
     assert torch.equal(out0["_render_alphas"], out["_render_alphas"])
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 4):
         prev = _lib.set_option("raster_fwd", v)
         try:
             with torch.no_grad():

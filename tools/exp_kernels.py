@@ -32,7 +32,8 @@ CONFIGS = [
     ("raster variant 1", {"raster_fwd": 1}),
     ("raster variant 2", {"raster_fwd": 2}),
     ("raster variant 3", {"raster_fwd": 3}),
-    ("raster variant 3, no blend", {"raster_fwd": 3, "debug1": 1}),
+    ("raster variant 4", {"raster_fwd": 4}),
+    ("raster variant 4, no blend", {"raster_fwd": 4, "debug1": 1}),
 ]
 
 
