@@ -409,7 +409,7 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
     const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int cap,
     unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
-    int32_t* __restrict__ flatten_ids) {
+    int32_t* __restrict__ flatten_ids, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);      // [cap]
     unsigned* boff = reinterpret_cast<unsigned*>(smem + (size_t)cap * 8);     // [2*cap + 1]
@@ -520,12 +520,14 @@ __global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
     }
     __syncthreads();
     // rank inside the sub-bucket by (depth bits, flat id) and write the final records
+    if (dbg & 2) return;
     for (int p = t; p < n; p += TS_THREADS) {
         const unsigned long long key = B[p];
         const int j = sub_bucket((unsigned)(key >> 32));
         const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
         unsigned r = beg;
         for (unsigned q = beg; q < end; ++q) r += (B[q] < key) ? 1u : 0u;
+        if (dbg & 1) { if (r == 0xffffffffu) flatten_ids[s] = 0; continue; }
         if (isect_ids) isect_ids[s + r] = hi_key | (long long)(key >> 32);
         flatten_ids[s + r] = (int32_t)(unsigned)key;
     }
@@ -654,7 +656,7 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
 #define SC_LAUNCH_BS(EV)                                                                                      \
     hipLaunchKernelGGL(tile_bucket_sort_kernel<EV>, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16 + 16, s,          \
                        (const uint2*)bucket, isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, cap, \
-                       needs_radix, isect_ids, flatten_ids)
+                       needs_radix, isect_ids, flatten_ids, g_sc_debug[2])
     if (cap <= 4 * TS_THREADS) SC_LAUNCH_BS(4);
     else if (cap <= 8 * TS_THREADS) SC_LAUNCH_BS(8);
     else if (cap <= 12 * TS_THREADS) SC_LAUNCH_BS(12);

@@ -27,6 +27,8 @@ CONFIGS = [
     ("scatter: no pass 2", {"debug0": 2}),
     ("scatter: no reservation atomics", {"debug0": 4}),
     ("raster: no blend loop", {"debug1": 1}),
+    ("bucket sort: no final stores", {"debug2": 1}),
+    ("bucket sort: no rank loop/stores", {"debug2": 2}),
     ("isect radix route", {"isect": "radix"}),
     ("raster variant 0", {"raster_fwd": 0}),
     ("raster variant 1", {"raster_fwd": 1}),
