@@ -92,32 +92,34 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
                                 sc_stream_t stream);
 
 /* Fused tile-bucketed path: produces exactly what count + emit + stable sort + offset-encode
- * produce (bit-identical isect_ids / flatten_ids / offsets) with one bucket pass and one
- * in-LDS sort per tile.  Two calls because the caller must size the outputs in between:
+ * produce (bit-identical isect_ids / flatten_ids / offsets): Gaussians are bucketed by SUPER-TILE
+ * (2x2 tiles), each super-tile is sorted once in LDS and its up-to-4 per-tile lists are emitted by
+ * a stable filter.  Two calls because the caller must size the outputs in between:
  *   sc_isect_bin_count : tiles_per_gauss, per-tile offsets (= isect_offset_encode result) and
- *                        meta_dev[0] = total intersections, meta_dev[1] = largest per-tile count
+ *                        meta_dev[0] = total intersections I, [1] = largest per-tile count,
+ *                        [2] = total (Gaussian, super-tile) records, [3] = largest super-tile
  *   sc_isect_bin_sort  : isect_ids / flatten_ids, sorted.  `capacity` = elements the output buffers
- *                        (and the workspace) were sized for, `tile_capacity` = largest per-tile
- *                        count the caller provisioned LDS for.  The kernels read meta_dev themselves
- *                        and do NOTHING when meta_dev[0] > capacity or meta_dev[1] > tile_capacity,
- *                        so a caller may launch with predicted sizes before it has read meta_dev
- *                        back (no GPU idle bubble) and retry with exact sizes if the prediction
- *                        was too small.
- * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384 or tile_capacity > 9216;
- * the caller then takes the count/emit/radix-sort route.
+ *                        were sized for, `rec_capacity` = records the workspace was sized for,
+ *                        `super_capacity` = largest super-tile the caller provisioned LDS for.  The
+ *                        kernels read meta_dev themselves and do NOTHING when meta_dev[0] > capacity,
+ *                        meta_dev[2] > rec_capacity or meta_dev[3] > super_capacity, so a caller may
+ *                        launch with predicted sizes before it has read meta_dev back (no GPU idle
+ *                        bubble) and retry with exact sizes if the prediction was too small.
+ * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384, C*N >= 2^28 or
+ * super_capacity > 7168; the caller then takes the count/emit/radix-sort route.
  */
-/* n_isects < 0: bytes of the count-phase workspace (shared by both calls; holds the spatial order
- * of the visible Gaussians); n_isects >= 0: bytes of the sort-phase workspace for that capacity. */
-size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_isects);
+/* n_records < 0: bytes of the count-phase workspace (shared by both calls; holds the spatial order
+ * of the visible Gaussians); n_records >= 0: bytes of the sort-phase workspace for that many records. */
+size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_records);
 int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
                        int tile_size, int tile_width, int tile_height,
-                       int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* meta_dev /* [2] */,
+                       int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* meta_dev /* [4] */,
                        void* workspace, size_t ws_bytes, sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
                       const int32_t* isect_offsets, const int64_t* meta_dev,
                       const void* count_workspace /* the one sc_isect_bin_count filled */,
-                      int64_t capacity, int64_t tile_capacity,
+                      int64_t capacity, int64_t rec_capacity, int64_t super_capacity,
                       int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
 

@@ -3,25 +3,31 @@
 // (street_gaussian/models/street_gaussian_renderer.py:243-253).
 //
 // The reference-shaped route (isect.hip + radix_sort.hip) moves every (key, value) pair through
-// HBM once per radix pass: 6 x 24 B x I.  The sort key is (camera, tile, depth bits), and the
+// HBM once per radix pass: 6 x 24 B x I.  The sort key is (camera, tile, depth bits) and the
 // number of (camera, tile) buckets is small (9600 at 1920x1280), so instead:
-//   1. bin_count      : per-workgroup LDS histograms -> global per-bucket counts -> exclusive scan
-//                       = isect_offsets (exactly isect_offset_encode's lower bounds), total, max.
-//                       The same pass histograms the visible Gaussians by the tile of their
-//                       CENTRE and a small counting sort (center_scatter) orders them spatially.
-//   2. bin_scatter    : walks the Gaussians in that spatial order, so the 4096 Gaussians of a
-//                       workgroup touch a compact strip of buckets: it reserves a slice of each
-//                       bucket it touches with ONE global atomic per (workgroup, bucket) and drops
-//                       8-byte (depth bits, flat id) records into its slices; records of one bucket
-//                       arrive in long runs, which is what makes the stores coalesce (in arrival
-//                       order of the Gaussians the same stores ran ~3x slower).
-//   3. tile_bucket_sort: one workgroup per bucket: interpolation sort in LDS on (depth bits, id);
-//                       degenerate tiles (many equal depths) fall back to tile_sort (ballot-ranked
-//                       stable LSD radix passes).
-// The required order is (depth bits, flat id): a stable sort of gaussian-major emission order
-// breaks depth ties by ascending flat id.  Integer work only: results are bit-identical to the
-// reference-shaped route (tests compare both against the oracle).
-// HBM traffic: ~(8 + 8 + 12) B x I instead of ~144 B x I.
+//
+//   1. bin_count  : every Gaussian adds the 4 corners of its tile rectangle to a 2-D DIFFERENCE
+//                   grid (LDS per workgroup, flushed with global atomics); a 2-D prefix sum of
+//                   that grid gives the exact number of rectangles covering each tile, and its
+//                   exclusive scan is isect_offsets (== isect_offset_encode's lower bounds) -- 4
+//                   atomics per Gaussian instead of one per (Gaussian, tile).  The same is done on
+//                   the grid of SUPER-TILES (2x2 tiles), plus a histogram of the visible Gaussians
+//                   by the super-tile of their rectangle's centre.
+//   2. center_scatter : counting sort of the visible Gaussians by that centre super-tile, so that
+//                   the next pass walks them in spatial order (stores into a bucket then arrive in
+//                   long runs and coalesce; in arrival order they ran ~3x slower).
+//   3. bin_scatter: one 8-byte record (depth bits, 4-bit tile mask | flat id) per (Gaussian,
+//                   SUPER-tile): 2.9x fewer records than (Gaussian, tile) pairs.  A workgroup
+//                   reserves its slice of each bucket with ONE global atomic per (workgroup, bucket).
+//   4. super_sort : one workgroup per super-tile sorts its records ONCE on (depth bits, flat id)
+//                   in LDS (interpolation sort; radix fallback for degenerate key distributions)
+//                   and then emits the up-to-4 per-tile lists by a stable, ballot-compacted filter
+//                   on the mask bit -- each emitted list is exactly the stable-sorted list of that
+//                   tile.  Stores are coalesced (consecutive lanes -> consecutive slots).
+//
+// Order contract: (depth bits, flat id) ascending == stable sort of gaussian-major emission order.
+// Integer work only: results are bit-identical to the reference-shaped route (tests compare both
+// against the oracle).  HBM traffic ~ 16 B x I/2.9 + 12 B x I instead of ~144 B x I.
 #include "sc_common.h"
 
 #pragma clang fp contract(off)
@@ -29,12 +35,24 @@
 namespace {
 
 constexpr int BIN_THREADS = 1024;
-constexpr int BIN_GPT = 4;                       // gaussians per thread
-constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;   // gaussians per workgroup
-constexpr int BIN_MAX_BUCKETS = 16384;           // (camera, tile) buckets that fit the LDS histograms
+constexpr int BIN_GPT = 4;                       // gaussians per thread in the count / centre passes
+constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
+constexpr int SCAT_THREADS = 256;
+constexpr int SCAT_GPT = 4;
+constexpr int SCAT_GPB = SCAT_THREADS * SCAT_GPT;
+constexpr int BIN_MAX_TILES = 16384;             // C * tile_width * tile_height handled by this path
 constexpr int BIN_BIG = 64;                      // rectangles larger than this are walked by a whole wave
+constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
+constexpr unsigned long long KEY_MASK = 0xffffffff0fffffffull;   // (depth, id) without the tile mask
 
 struct Rect { int x0, x1, y0, y1; };
+
+struct Geo {
+    int tile_width, tile_height, T;      // tiles
+    int ss;                              // super-tile shift (1: 2x2 tiles, 0: super-tile == tile)
+    int stw, sth, ST;                    // super-tiles
+    int N;
+};
 
 // identical to isect.hip's tile_rect
 __device__ __forceinline__ Rect tile_rect(float mx, float my, int radius, float tile_size,
@@ -51,95 +69,69 @@ __device__ __forceinline__ Rect tile_rect(float mx, float my, int radius, float 
     return r;
 }
 
-// Calls f(bucket, pa, pb) once for every tile of this lane's rectangle, where (pa, pb) is the
-// owning lane's payload.  Rectangles with more than BIN_BIG tiles are spread over the 64 lanes of
-// the wave (the payload is broadcast while the wave is still converged).  All lanes of a wave
-// must call this together.
-template <typename F>
-__device__ __forceinline__ void walk_rect(const Rect& r, int cnt, int bucket_base, int tile_width,
-                                          unsigned pa, unsigned pb, F&& f) {
-    const int w = r.x1 - r.x0;
-    if (cnt > 0 && cnt <= BIN_BIG) {
-        for (int ty = r.y0; ty < r.y1; ++ty) {
-            const int row = bucket_base + ty * tile_width;
-            for (int tx = r.x0; tx < r.x1; ++tx) f(row + tx, pa, pb);
-        }
-    }
-    unsigned long long big = __ballot(cnt > BIN_BIG);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int bx0 = __shfl(r.x0, src, 64), by0 = __shfl(r.y0, src, 64);
-        const int bw = __shfl(w, src, 64), bcnt = __shfl(cnt, src, 64);
-        const int bbase = __shfl(bucket_base, src, 64);
-        const unsigned ba = (unsigned)__shfl((int)pa, src, 64), bb = (unsigned)__shfl((int)pb, src, 64);
-        for (int s = sc_lane(); s < bcnt; s += 64) {
-            const int ty = by0 + s / bw, tx = bx0 + s % bw;
-            f(bbase + ty * tile_width + tx, ba, bb);
-        }
-    }
+// the super-tile rectangle covered by a non-empty tile rectangle
+__device__ __forceinline__ Rect super_rect(const Rect& r, int ss) {
+    Rect s;
+    s.x0 = r.x0 >> ss; s.y0 = r.y0 >> ss;
+    s.x1 = ((r.x1 - 1) >> ss) + 1; s.y1 = ((r.y1 - 1) >> ss) + 1;
+    return s;
 }
 
-// ---- pass 1: counts -----------------------------------------------------------------------------
-// counts[b]  += number of rectangles covering bucket b          (-> isect_offsets)
-// ccounts[b] += number of visible Gaussians whose CENTRE tile is b (-> spatial order)
+// ---- pass 1: counts ---------------------------------------------------------------------------
+// dgrid_t : [C][th+1][tw+1]   2-D difference grid over tiles        (-> per-tile counts)
+// dgrid_s : [C][sth+1][stw+1] 2-D difference grid over super-tiles  (-> records per super-tile)
+// chist   : [C][sth][stw]     visible Gaussians by centre super-tile
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
-    const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, int N,
-    float tile_size, int tile_width, int tile_height, int n_buckets,
-    int32_t* __restrict__ tiles_per_gauss, unsigned* __restrict__ counts,
-    unsigned* __restrict__ ccounts) {
-    extern __shared__ unsigned lds[];
-    unsigned* hist = lds;                 // [n_buckets]
-    unsigned* chist = lds + n_buckets;    // [n_buckets]
-    for (int b = threadIdx.x; b < 2 * n_buckets; b += BIN_THREADS) lds[b] = 0;
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, Geo g,
+    float tile_size, int C, int32_t* __restrict__ tiles_per_gauss, int* __restrict__ dgrid_t,
+    int* __restrict__ dgrid_s, unsigned* __restrict__ chist) {
+    extern __shared__ int lds_i[];
+    const int nt = C * (g.tile_height + 1) * (g.tile_width + 1);
+    const int ns = g.ss ? C * (g.sth + 1) * (g.stw + 1) : 0;
+    const int nc = C * g.ST;
+    int* dt = lds_i;
+    int* ds = lds_i + nt;
+    int* ch = lds_i + nt + ns;
+    for (int i = threadIdx.x; i < nt + ns + nc; i += BIN_THREADS) lds_i[i] = 0;
     __syncthreads();
-    const int T = tile_width * tile_height;
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
         const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
-        Rect r = {0, 0, 0, 0};
-        int cnt = 0, bbase = 0;
-        if (i < CN) {
-            const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
-            r = tile_rect(m.x, m.y, radii[i], tile_size, tile_width, tile_height);
-            cnt = (r.y1 - r.y0) * (r.x1 - r.x0);
-            tiles_per_gauss[i] = cnt;
-            bbase = (int)(i / N) * T;
-            if (cnt > 0) {
-                // centre of the (non-empty) rectangle: a tile the Gaussian is filed under
-                const int cx = (r.x0 + r.x1 - 1) >> 1, cy = (r.y0 + r.y1 - 1) >> 1;
-                atomicAdd(&chist[bbase + cy * tile_width + cx], 1u);
-            }
+        if (i >= CN) continue;
+        const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
+        const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
+        const int cnt = (r.y1 - r.y0) * (r.x1 - r.x0);
+        tiles_per_gauss[i] = cnt;
+        if (cnt <= 0) continue;
+        const int cam = (int)(i / g.N);
+        {
+            const int w = g.tile_width + 1;
+            int* d = dt + cam * (g.tile_height + 1) * w;
+            atomicAdd(&d[r.y0 * w + r.x0], 1);  atomicAdd(&d[r.y0 * w + r.x1], -1);
+            atomicAdd(&d[r.y1 * w + r.x0], -1); atomicAdd(&d[r.y1 * w + r.x1], 1);
         }
-        walk_rect(r, cnt, bbase, tile_width, 0u, 0u,
-                  [&](int bucket, unsigned, unsigned) { atomicAdd(&hist[bucket], 1u); });
+        const Rect s = super_rect(r, g.ss);
+        if (g.ss) {
+            const int w = g.stw + 1;
+            int* d = ds + cam * (g.sth + 1) * w;
+            atomicAdd(&d[s.y0 * w + s.x0], 1);  atomicAdd(&d[s.y0 * w + s.x1], -1);
+            atomicAdd(&d[s.y1 * w + s.x0], -1); atomicAdd(&d[s.y1 * w + s.x1], 1);
+        }
+        const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
+        atomicAdd(&ch[cam * g.ST + cy * g.stw + cx], 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
-        const unsigned c = hist[b], cc = chist[b];
-        if (c) atomicAdd(&counts[b], c);
-        if (cc) atomicAdd(&ccounts[b], cc);
-    }
+    for (int i = threadIdx.x; i < nt; i += BIN_THREADS) { const int v = dt[i]; if (v) atomicAdd(&dgrid_t[i], v); }
+    for (int i = threadIdx.x; i < ns; i += BIN_THREADS) { const int v = ds[i]; if (v) atomicAdd(&dgrid_s[i], v); }
+    for (int i = threadIdx.x; i < nc; i += BIN_THREADS) { const int v = ch[i]; if (v) atomicAdd(&chist[i], (unsigned)v); }
 }
 
-// single workgroup: out = exclusive scan of counts; meta[0] = total, meta[1] = max count.
-// Thread t owns `per` consecutive counters (one pass, one block scan).
-__global__ __launch_bounds__(1024) void bin_scan_kernel(const unsigned* __restrict__ counts, int n_buckets,
-                                                        int32_t* __restrict__ out,
-                                                        int64_t* __restrict__ meta) {
-    __shared__ long long wave_tot[16];
-    __shared__ unsigned wave_max[16];
-    const int t = threadIdx.x, lane = sc_lane(), wave = t >> 6;
-    const int per = (n_buckets + 1023) / 1024;
-    const int beg = t * per, end = min(beg + per, n_buckets);
-    long long sum = 0;
-    unsigned mx = 0;
-    for (int i = beg; i < end; ++i) {
-        const unsigned c = counts[i];
-        sum += c;
-        mx = max(mx, c);
-    }
+// block-wide exclusive scan helper (1024 threads): returns the exclusive prefix of `sum`, the
+// grand total in *total and the block maximum of `mx` in *maxv.
+__device__ __forceinline__ long long block_scan_1024(long long sum, unsigned mx, long long* total,
+                                                     unsigned* maxv, long long* wave_tot, unsigned* wave_max) {
+    const int lane = sc_lane(), wave = threadIdx.x >> 6;
     const long long incl = sc_wave_incl_scan64(sum);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
@@ -154,26 +146,81 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(const unsigned* __restri
         tot += wave_tot[w];
         m = max(m, wave_max[w]);
     }
-    for (int i = beg; i < end; ++i) {
-        const unsigned c = counts[i];
-        out[i] = (int32_t)run;
-        run += c;
+    *total = tot;
+    *maxv = m;
+    return run;
+}
+
+// single workgroup: 2-D prefix sum of a difference grid [C][gh+1][gw+1] -> per-cell counts ->
+// exclusive scan in (camera, row, column) order -> out[C*gh*gw]; meta[0] = total, meta[1] = max.
+__global__ __launch_bounds__(1024) void grid_scan_kernel(const int* __restrict__ dgrid, int C, int gw, int gh,
+                                                         int32_t* __restrict__ out, int64_t* __restrict__ meta) {
+    extern __shared__ int grid[];
+    __shared__ long long wave_tot[16];
+    __shared__ unsigned wave_max[16];
+    const int t = threadIdx.x;
+    const int W = gw + 1, H = gh + 1, ncell = C * H * W;
+    for (int i = t; i < ncell; i += 1024) grid[i] = dgrid[i];
+    __syncthreads();
+    for (int r = t; r < C * H; r += 1024) {          // prefix along x
+        int* row = grid + r * W;
+        int run = 0;
+        for (int x = 0; x < W; ++x) { run += row[x]; row[x] = run; }
     }
+    __syncthreads();
+    for (int c = t; c < C * W; c += 1024) {          // prefix along y
+        const int cam = c / W, x = c - cam * W;
+        int* col = grid + cam * H * W + x;
+        int run = 0;
+        for (int y = 0; y < H; ++y) { run += col[y * W]; col[y * W] = run; }
+    }
+    __syncthreads();
+    const int n = C * gh * gw;
+    const int per = (n + 1023) / 1024;
+    const int beg = t * per, end = min(beg + per, n);
+    auto cell = [&](int i) -> unsigned {
+        const int cam = i / (gh * gw), rem = i - cam * gh * gw;
+        const int y = rem / gw, x = rem - y * gw;
+        return (unsigned)grid[(cam * H + y) * W + x];
+    };
+    long long sum = 0;
+    unsigned mx = 0;
+    for (int i = beg; i < end; ++i) { const unsigned c = cell(i); sum += c; mx = max(mx, c); }
+    long long tot;
+    unsigned m;
+    long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
+    for (int i = beg; i < end; ++i) { out[i] = (int32_t)run; run += cell(i); }
     if (t == 0) { meta[0] = tot; meta[1] = (long long)m; }
 }
 
-// ---- spatial order: counting sort of the visible Gaussians by centre tile -------------------------
+// single workgroup: out = exclusive scan of counts; meta[0] = total, meta[1] = max count
+__global__ __launch_bounds__(1024) void hist_scan_kernel(const unsigned* __restrict__ counts, int n,
+                                                         int32_t* __restrict__ out, int64_t* __restrict__ meta) {
+    __shared__ long long wave_tot[16];
+    __shared__ unsigned wave_max[16];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int beg = t * per, end = min(beg + per, n);
+    long long sum = 0;
+    unsigned mx = 0;
+    for (int i = beg; i < end; ++i) { const unsigned c = counts[i]; sum += c; mx = max(mx, c); }
+    long long tot;
+    unsigned m;
+    long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
+    for (int i = beg; i < end; ++i) { out[i] = (int32_t)run; run += counts[i]; }
+    if (t == 0) { meta[0] = tot; meta[1] = (long long)m; }
+}
+
+// ---- spatial order: counting sort of the visible Gaussians by centre super-tile --------------------
 __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
-    const int32_t* __restrict__ radii, int64_t CN, int N, float tile_size, int tile_width,
-    int tile_height, int n_buckets, const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor,
-    int32_t* __restrict__ perm) {
+    const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
+    const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor, int32_t* __restrict__ perm) {
     extern __shared__ unsigned lds[];
-    unsigned* hist = lds;               // [n_buckets]
-    unsigned* gbase = lds + n_buckets;  // [n_buckets]
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
+    unsigned* hist = lds;                // [n_sbuckets]
+    unsigned* gbase = lds + n_sbuckets;  // [n_sbuckets]
+    for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) hist[b] = 0;
     __syncthreads();
-    const int T = tile_width * tile_height;
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
     int cb[BIN_GPT];
 #pragma unroll
@@ -182,14 +229,15 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         cb[k] = -1;
         if (i < CN && tiles_per_gauss[i] > 0) {
             const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
-            const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, tile_width, tile_height);
-            const int cx = (r.x0 + r.x1 - 1) >> 1, cy = (r.y0 + r.y1 - 1) >> 1;
-            cb[k] = (int)(i / N) * T + cy * tile_width + cx;
+            const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
+            const Rect s = super_rect(r, g.ss);
+            const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
+            cb[k] = (int)(i / g.N) * g.ST + cy * g.stw + cx;
             atomicAdd(&hist[cb[k]], 1u);
         }
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
+    for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) {
         const unsigned c = hist[b];
         if (c) gbase[b] = (unsigned)cstart[b] + atomicAdd(&ccursor[b], c);
         hist[b] = 0;
@@ -203,63 +251,278 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 }
 
 // ---- pass 2: records ------------------------------------------------------------------------------
-__global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(
+// Calls f(bucket, mask, depth, id) for every super-tile of this lane's super rectangle; rectangles
+// with more than BIN_BIG super-tiles are spread over the 64 lanes of the wave.  `mask` has bit
+// (dy << ss | dx) set when tile (2sx+dx, 2sy+dy) lies inside the Gaussian's tile rectangle.
+template <typename F>
+__device__ __forceinline__ void walk_super(const Rect& r, bool live, int cam_base, const Geo& g,
+                                           unsigned depth, unsigned id, F&& f) {
+    const Rect s = live ? super_rect(r, g.ss) : Rect{0, 0, 0, 0};
+    const int sw = s.x1 - s.x0, cnt = sw * (s.y1 - s.y0);
+    auto mask_of = [&](int x0, int x1, int y0, int y1, int sx, int sy) -> unsigned {
+        if (!g.ss) return 1u;
+        unsigned m = 0;
+        const int tx = sx << 1, ty = sy << 1;
+        if (ty >= y0 && ty < y1) { if (tx >= x0 && tx < x1) m |= 1u; if (tx + 1 >= x0 && tx + 1 < x1) m |= 2u; }
+        if (ty + 1 >= y0 && ty + 1 < y1) { if (tx >= x0 && tx < x1) m |= 4u; if (tx + 1 >= x0 && tx + 1 < x1) m |= 8u; }
+        return m;
+    };
+    if (cnt > 0 && cnt <= BIN_BIG) {
+        for (int sy = s.y0; sy < s.y1; ++sy)
+            for (int sx = s.x0; sx < s.x1; ++sx)
+                f(cam_base + sy * g.stw + sx, mask_of(r.x0, r.x1, r.y0, r.y1, sx, sy), depth, id);
+    }
+    unsigned long long big = __ballot(cnt > BIN_BIG);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __shfl(s.x0, src, 64), by0 = __shfl(s.y0, src, 64);
+        const int bw = __shfl(sw, src, 64), bcnt = __shfl(cnt, src, 64), bbase = __shfl(cam_base, src, 64);
+        const int rx0 = __shfl(r.x0, src, 64), rx1 = __shfl(r.x1, src, 64);
+        const int ry0 = __shfl(r.y0, src, 64), ry1 = __shfl(r.y1, src, 64);
+        const unsigned bd = (unsigned)__shfl((int)depth, src, 64), bi = (unsigned)__shfl((int)id, src, 64);
+        for (int q = sc_lane(); q < bcnt; q += 64) {
+            const int sy = by0 + q / bw, sx = bx0 + q % bw;
+            f(bbase + sy * g.stw + sx, mask_of(rx0, rx1, ry0, ry1, sx, sy), bd, bi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ depths, const int32_t* __restrict__ perm,
-    const int64_t* __restrict__ n_visible, int N, float tile_size, int tile_width,
-    int tile_height, int n_buckets, const int32_t* __restrict__ offsets,
-    const int64_t* __restrict__ meta, int64_t capacity, int64_t tile_capacity,
-    unsigned* __restrict__ cursor, uint2* __restrict__ bucket, int dbg) {
+    const int64_t* __restrict__ n_visible, Geo g, float tile_size, int n_sbuckets,
+    const int32_t* __restrict__ soffsets, const int64_t* __restrict__ meta, int64_t capacity,
+    int64_t rec_capacity, int64_t super_capacity, unsigned* __restrict__ cursor,
+    uint2* __restrict__ records, int dbg) {
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
-    if (meta[0] > capacity || meta[1] > tile_capacity) return;
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     const int64_t M = n_visible[0];
-    const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
+    const int64_t base = (int64_t)blockIdx.x * SCAT_GPB;
     if (base >= M) return;
-    unsigned* hist = lds;               // [n_buckets] counts, then running local cursors
-    unsigned* gbase = lds + n_buckets;  // [n_buckets] global start of this workgroup's slice
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) hist[b] = 0;
+    unsigned* hist = lds;                  // [n_sbuckets] counts, then running local cursors
+    unsigned* gbase = lds + n_sbuckets;    // [n_sbuckets] global start of this workgroup's slice
+    for (int b = threadIdx.x; b < n_sbuckets; b += SCAT_THREADS) hist[b] = 0;
     __syncthreads();
-    const int T = tile_width * tile_height;
-    Rect rr[BIN_GPT];
-    int cc[BIN_GPT], bb[BIN_GPT];
-    unsigned dd[BIN_GPT], ii[BIN_GPT];
+    Rect rr[SCAT_GPT];
+    bool live[SCAT_GPT];
+    int cb[SCAT_GPT];
+    unsigned dd[SCAT_GPT], ii[SCAT_GPT];
 #pragma unroll
-    for (int k = 0; k < BIN_GPT; ++k) {
+    for (int k = 0; k < SCAT_GPT; ++k) {
         // consecutive lanes take consecutive Gaussians of the spatial order
-        const int64_t j = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+        const int64_t j = base + (int64_t)k * SCAT_THREADS + threadIdx.x;
         rr[k] = {0, 0, 0, 0};
-        cc[k] = 0; bb[k] = 0; dd[k] = 0; ii[k] = 0;
-        if (j < M) {
+        live[k] = j < M;
+        cb[k] = 0; dd[k] = 0; ii[k] = 0;
+        if (live[k]) {
             const int64_t i = perm[j];
             const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
-            rr[k] = tile_rect(m.x, m.y, radii[i], tile_size, tile_width, tile_height);
-            cc[k] = (rr[k].y1 - rr[k].y0) * (rr[k].x1 - rr[k].x0);
-            bb[k] = (int)(i / N) * T;
+            rr[k] = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
+            cb[k] = (int)(i / g.N) * g.ST;
             dd[k] = __float_as_uint(depths[i]);
             ii[k] = (unsigned)i;
         }
-        walk_rect(rr[k], cc[k], bb[k], tile_width, 0u, 0u,
-                  [&](int b, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
+        walk_super(rr[k], live[k], cb[k], g, 0u, 0u,
+                   [&](int b, unsigned, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < n_buckets; b += BIN_THREADS) {
+    for (int b = threadIdx.x; b < n_sbuckets; b += SCAT_THREADS) {
         const unsigned c = hist[b];
-        if (c) gbase[b] = (unsigned)offsets[b] + ((dbg & 4) ? 0u : atomicAdd(&cursor[b], c));
+        if (c) gbase[b] = (unsigned)soffsets[b] + ((dbg & 4) ? 0u : atomicAdd(&cursor[b], c));
         hist[b] = 0;
     }
     __syncthreads();
     if (dbg & 2) return;
 #pragma unroll
-    for (int k = 0; k < BIN_GPT; ++k) {
-        walk_rect(rr[k], cc[k], bb[k], tile_width, dd[k], ii[k], [&](int b, unsigned d, unsigned id) {
+    for (int k = 0; k < SCAT_GPT; ++k) {
+        walk_super(rr[k], live[k], cb[k], g, dd[k], ii[k], [&](int b, unsigned mask, unsigned d, unsigned id) {
             const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
-            if (!(dbg & 1)) bucket[slot] = make_uint2(d, id);
+            if (!(dbg & 1)) records[slot] = make_uint2(d, id | (mask << 28));
         });
     }
 }
 
-// ---- per-tile LDS sort: radix fallback -------------------------------------------------------------
+// ---- pass 3: per-super-tile sort + emit ---------------------------------------------------------------
+constexpr int SS_THREADS = 512;
+constexpr int SS_WAVES = SS_THREADS / 64;
+
+// Emits the per-tile lists of one super-tile from its records sorted on (depth, id) in LDS.
+// Stable filter per tile: rank of record i in tile k's list = number of records j < i with mask bit k;
+// computed per (round, wave) with ballots, bases by a tiny scan over the (round, wave) table.
+template <int THREADS>
+__device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict__ S, int n, int sb, const Geo& g,
+                                           const int32_t* __restrict__ offsets, int n_tiles_total,
+                                           int64_t n_isects, int tile_bits, unsigned long long* table,
+                                           int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
+                                           int dbg) {
+    constexpr int WAVES = THREADS / 64;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cam = sb / g.ST, srem = sb - cam * g.ST;
+    const int sy = srem / g.stw, sx = srem - sy * g.stw;
+    const int ntile = g.ss ? 4 : 1;
+    const int rounds = (n + THREADS - 1) / THREADS;
+    // pass A: per (round, wave) packed counts (16 bits per tile; a tile list has <= 9216 entries)
+    for (int r = 0; r < rounds; ++r) {
+        const int i = r * THREADS + t;
+        const unsigned m = (i < n) ? (unsigned)((S[i] >> 28) & 0xfu) : 0u;
+        unsigned long long packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            packed |= (unsigned long long)__popcll(__ballot((m >> k) & 1u)) << (16 * k);
+        if (lane == 0) table[r * WAVES + wave] = packed;
+    }
+    __syncthreads();
+    // exclusive scan of the table (<= rounds * WAVES entries) by the first wave
+    if (wave == 0) {
+        const int cnt = rounds * WAVES;
+        unsigned long long carry = 0;
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+            const int i = b0 + lane;
+            const unsigned long long v = (i < cnt) ? table[i] : 0ull;
+            const unsigned long long incl = (unsigned long long)sc_wave_incl_scan64((long long)v);
+            if (i < cnt) table[i] = carry + incl - v;
+            carry += (unsigned long long)__shfl((long long)incl, 63, 64);
+        }
+    }
+    __syncthreads();
+    // tile bases
+    long long hi_key[4];
+    int tbase[4];
+    bool tok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tx = (sx << g.ss) + (k & 1), ty = (sy << g.ss) + (k >> 1);
+        tok[k] = (k < ntile) && tx < g.tile_width && ty < g.tile_height;
+        const int tile = ty * g.tile_width + tx;
+        tbase[k] = tok[k] ? offsets[cam * g.T + tile] : 0;
+        hi_key[k] = ((long long)cam << (32 + tile_bits)) | ((long long)tile << 32);
+    }
+    (void)n_tiles_total; (void)n_isects;
+    if (dbg & 1) return;
+    for (int r = 0; r < rounds; ++r) {
+        const int i = r * THREADS + t;
+        const unsigned long long key = (i < n) ? S[i] : 0ull;
+        const unsigned m = (i < n) ? (unsigned)((key >> 28) & 0xfu) : 0u;
+        const unsigned long long base = table[r * WAVES + wave];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long bal = __ballot((m >> k) & 1u);
+            if (((m >> k) & 1u) && tok[k]) {
+                const int pos = tbase[k] + (int)((base >> (16 * k)) & 0xffffu) + __popcll(bal & sc_lanemask_lt());
+                if (isect_ids) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
+                flatten_ids[pos] = (int32_t)((unsigned)key & ID_MASK);
+            }
+        }
+    }
+}
+
+// interpolation sort: the common path.  Records are spread over `nbk` sub-buckets by a MONOTONE map
+// of the depth bit pattern, grouped by one counting pass, and ranked inside their sub-bucket by
+// counting smaller (depth, id) keys.  A super-tile whose keys pile up in one sub-bucket (occupancy
+// > BS_MAX_OCC, e.g. hundreds of equal depths) is flagged and left to super_radix_kernel.
+constexpr int BS_MAX_OCC = 48;
+
+__global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
+    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, Geo g,
+    const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
+    int64_t rec_capacity, int tile_bits, int cap, int per_thread, unsigned char* __restrict__ needs_radix,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    // [B: cap u64][S: cap u64][boff: SS_THREADS*per_thread + 1 u32][table]
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* S = B + cap;
+    unsigned* boff = reinterpret_cast<unsigned*>(S + cap);
+    const int nbk = SS_THREADS * per_thread;
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(boff + ((nbk + 2) & ~1));
+    __shared__ unsigned red_lo[SS_WAVES], red_hi[SS_WAVES], red_sum[SS_WAVES], red_occ[SS_WAVES];
+
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > (int64_t)cap) return;
+    const int sb = blockIdx.x;
+    const int s = soffsets[sb];
+    const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
+    const int n = e - s;
+    if (n <= 0) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    for (int i = t; i <= nbk; i += SS_THREADS) boff[i] = 0;
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = t; i < n; i += SS_THREADS) {
+        const unsigned d = records[s + i].x;
+        lo = min(lo, d);
+        hi = max(hi, d);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+    }
+    if (lane == 0) { red_lo[wave] = lo; red_hi[wave] = hi; }
+    __syncthreads();
+    lo = red_lo[0]; hi = red_hi[0];
+#pragma unroll
+    for (int w = 1; w < SS_WAVES; ++w) { lo = min(lo, red_lo[w]); hi = max(hi, red_hi[w]); }
+    const float scale = (float)nbk / ((float)(hi - lo) + 1.0f);
+    auto sub_bucket = [&](unsigned d) -> int {
+        const int v = (int)((float)(d - lo) * scale);     // monotone in d
+        return min(v, nbk - 1);
+    };
+    for (int i = t; i < n; i += SS_THREADS) atomicAdd(&boff[sub_bucket(records[s + i].x)], 1u);
+    __syncthreads();
+    // exclusive scan: thread t owns per_thread consecutive counters (per_thread is ODD: the
+    // lanes' strides then hit 32 distinct banks instead of two)
+    unsigned sum = 0, occ = 0;
+    for (int k = 0; k < per_thread; ++k) {
+        const unsigned c = boff[t * per_thread + k];
+        sum += c;
+        occ = max(occ, c);
+    }
+    const unsigned incl = (unsigned)sc_wave_incl_scan((int)sum);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) occ = max(occ, (unsigned)__shfl_xor((int)occ, o, 64));
+    if (lane == 63) red_sum[wave] = incl;
+    if (lane == 0) red_occ[wave] = occ;
+    __syncthreads();
+    occ = red_occ[0];
+#pragma unroll
+    for (int w = 1; w < SS_WAVES; ++w) occ = max(occ, red_occ[w]);
+    if (occ > BS_MAX_OCC) {                     // workgroup-uniform
+        if (t == 0) needs_radix[sb] = 1;
+        return;
+    }
+    unsigned run = incl - sum;
+#pragma unroll
+    for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
+    for (int k = 0; k < per_thread; ++k) {      // counts -> sub-bucket starts (used as running cursors)
+        const unsigned c = boff[t * per_thread + k];
+        boff[t * per_thread + k] = run;
+        run += c;
+    }
+    __syncthreads();
+    // scatter: after this pass boff[j] is the END of sub-bucket j (== start of j+1)
+    for (int i = t; i < n; i += SS_THREADS) {
+        const uint2 r = records[s + i];
+        const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
+        B[slot] = ((unsigned long long)r.x << 32) | r.y;
+    }
+    __syncthreads();
+    if (dbg & 2) return;
+    // rank inside the sub-bucket by (depth bits, flat id) -> sorted array S
+    for (int p = t; p < n; p += SS_THREADS) {
+        const unsigned long long key = B[p];
+        const unsigned long long kk = key & KEY_MASK;
+        const int j = sub_bucket((unsigned)(key >> 32));
+        const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
+        unsigned r = beg;
+        for (unsigned q = beg; q < end; ++q) r += ((B[q] & KEY_MASK) < kk) ? 1u : 0u;
+        S[r] = key;
+    }
+    __syncthreads();
+    emit_tiles<SS_THREADS>(S, n, sb, g, offsets, 0, 0, tile_bits, table, isect_ids, flatten_ids, dbg);
+}
+
+// ---- radix fallback for flagged super-tiles --------------------------------------------------------------
 constexpr int TS_THREADS = 256;
 constexpr int TS_WAVES = 4;
 
@@ -315,61 +578,49 @@ __device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ s
     __syncthreads();
 }
 
-__global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
-    const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
-    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int id_bits, int cap,
-    const unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
-    int32_t* __restrict__ flatten_ids) {
+// Persistent-style grid: every workgroup strides over the super-tiles and sorts only the flagged
+// ones (normally none: the launch then costs a few hundred flag reads).
+__global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
+    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, Geo g,
+    const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
+    int64_t rec_capacity, int tile_bits, int id_bits, int cap, const unsigned char* __restrict__ needs_radix,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);
-    unsigned long long* B = A + cap;
+    unsigned long long* Bb = A + cap;
+    unsigned long long* table = Bb + cap;
     __shared__ unsigned h[TS_WAVES][256];
     __shared__ unsigned wtot[TS_WAVES];
     __shared__ unsigned diff_s;
-    __shared__ int tie_s;
-
-    if (meta[0] > capacity || meta[1] > (int64_t)cap) return;    // undersized prediction: caller retries
-    const int b = blockIdx.x;
-    if (needs_radix && !needs_radix[b]) return;                  // already sorted by tile_bucket_sort_kernel
-    const int s = offsets[b];
-    const int e = (b + 1 < n_buckets) ? offsets[b + 1] : (int)meta[0];
-    const int n = e - s;
-    if (n <= 0) return;
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > (int64_t)cap) return;
     const int t = threadIdx.x;
-    if (t == 0) { diff_s = 0; tie_s = 0; }
-    __syncthreads();
-    const unsigned first_depth = bucket[s].x;
-    unsigned diff = 0;
-    for (int i = t; i < n; i += TS_THREADS) {
-        const uint2 r = bucket[s + i];
-        A[i] = ((unsigned long long)r.x << 32) | r.y;
-        diff |= r.x ^ first_depth;
-    }
+    for (int sb = blockIdx.x; sb < n_sbuckets; sb += gridDim.x) {
+        if (!needs_radix[sb]) continue;              // workgroup-uniform
+        const int s = soffsets[sb];
+        const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
+        const int n = e - s;
+        if (n <= 0) continue;
+        __syncthreads();
+        if (t == 0) diff_s = 0;
+        __syncthreads();
+        const unsigned first_depth = records[s].x;
+        unsigned diff = 0;
+        for (int i = t; i < n; i += TS_THREADS) {
+            const uint2 r = records[s + i];
+            A[i] = ((unsigned long long)r.x << 32) | r.y;
+            diff |= r.x ^ first_depth;
+        }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) diff |= (unsigned)__shfl_xor((int)diff, o, 64);
-    if ((t & 63) == 0 && diff) atomicOr(&diff_s, diff);
-    __syncthreads();
-    const int sig = 32 - __clz((int)diff_s);          // significant depth bits (0 when all equal)
-    int chunk = (n + TS_WAVES - 1) / TS_WAVES;
-    chunk = (chunk + 63) & ~63;
-
-    unsigned long long* src = A;
-    unsigned long long* dst = B;
-    // stable LSD passes over the significant depth bits only ...
-    for (int done = 0; done < sig;) {
-        const int bits = min(8, sig - done);
-        ts_pass(src, dst, n, chunk, 32 + done, bits, h, wtot);
-        unsigned long long* tmp = src; src = dst; dst = tmp;
-        done += bits;
-    }
-    // ... any two neighbours with the same depth bits? (ties must be ordered by flat id)
-    int tie = 0;
-    for (int i = t; i + 1 < n; i += TS_THREADS)
-        tie |= ((unsigned)(src[i] >> 32) == (unsigned)(src[i + 1] >> 32));
-    if (tie) tie_s = 1;
-    __syncthreads();
-    if (tie_s) {
-        // full (depth, id) key.  LSD: id bits first, then the depth bits again.
+        for (int o = 32; o >= 1; o >>= 1) diff |= (unsigned)__shfl_xor((int)diff, o, 64);
+        if ((t & 63) == 0 && diff) atomicOr(&diff_s, diff);
+        __syncthreads();
+        const int sig = 32 - __clz((int)diff_s);      // significant depth bits (0 when all equal)
+        int chunk = (n + TS_WAVES - 1) / TS_WAVES;
+        chunk = (chunk + 63) & ~63;
+        unsigned long long* src = A;
+        unsigned long long* dst = Bb;
+        // LSD on the full (depth, id) key: id bits first (bits 28..31 hold the tile mask and are
+        // skipped), then the significant depth bits
         for (int done = 0; done < id_bits;) {
             const int bits = min(8, id_bits - done);
             ts_pass(src, dst, n, chunk, done, bits, h, wtot);
@@ -382,182 +633,60 @@ __global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(
             unsigned long long* tmp = src; src = dst; dst = tmp;
             done += bits;
         }
-    }
-    const long long cam = b / tiles_per_cam, tile = b % tiles_per_cam;
-    const long long hi = (cam << (32 + tile_bits)) | (tile << 32);
-    for (int i = t; i < n; i += TS_THREADS) {
-        const unsigned long long k = src[i];
-        if (isect_ids) isect_ids[s + i] = hi | (long long)(k >> 32);
-        flatten_ids[s + i] = (int32_t)(unsigned)k;
-    }
-}
-
-// ---- per-tile interpolation (bucket) sort: the common path ---------------------------------------
-// The depth keys of one tile are spread over 2n sub-buckets by a MONOTONE map of their bit
-// pattern (so sub-bucket order == key order for any input, NaN and negative patterns included);
-// one counting pass groups the records by sub-bucket, then every record finds its final rank by
-// counting the smaller (depth, id) keys inside its own sub-bucket (expected occupancy < 1).  One
-// histogram + one scan + one scatter + one short rank loop instead of 4-7 ballot-ranked radix
-// passes.  A tile whose keys pile up in one sub-bucket (occupancy > BS_MAX_OCC, e.g. hundreds of
-// equal depths) is flagged and left to tile_sort_kernel.
-constexpr int BS_MAX_OCC = 48;
-
-// E > 0: every thread keeps its <= E records in registers (one global read per record, tiles up to
-// 256*E records); E == 0: records are re-read from global/L2 in each of the three passes.
-template <int E>
-__global__ __launch_bounds__(TS_THREADS) void tile_bucket_sort_kernel(
-    const uint2* __restrict__ bucket, const int32_t* __restrict__ offsets, int n_buckets,
-    const int64_t* __restrict__ meta, int64_t capacity, int tiles_per_cam, int tile_bits, int cap,
-    unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
-    int32_t* __restrict__ flatten_ids, int dbg) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);      // [cap]
-    unsigned* boff = reinterpret_cast<unsigned*>(smem + (size_t)cap * 8);     // [2*cap + 1]
-    __shared__ unsigned red_lo[TS_WAVES], red_hi[TS_WAVES], red_sum[TS_WAVES], red_occ[TS_WAVES];
-
-    if (meta[0] > capacity || meta[1] > (int64_t)cap) return;    // undersized prediction: caller retries
-    const int b = blockIdx.x;
-    const int s = offsets[b];
-    const int e = (b + 1 < n_buckets) ? offsets[b + 1] : (int)meta[0];
-    const int n = e - s;
-    if (n <= 0) return;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long long cam = b / tiles_per_cam, tile = b % tiles_per_cam;
-    const long long hi_key = (cam << (32 + tile_bits)) | (tile << 32);
-
-    // number of sub-buckets: 2n rounded up to a multiple of 256 (fits: n <= cap, boff holds 2*cap+1)
-    const int nbk = ((2 * n + TS_THREADS - 1) / TS_THREADS) * TS_THREADS;
-    const int per_thread = nbk / TS_THREADS;
-    for (int i = t; i <= nbk; i += TS_THREADS) boff[i] = 0;
-
-    constexpr int EE = E > 0 ? E : 1;
-    uint2 rec[EE];
-    unsigned lo = 0xffffffffu, hi = 0u;
-    if constexpr (E > 0) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int i = t + k * TS_THREADS;
-            rec[k] = make_uint2(0u, 0u);
-            if (i < n) {
-                rec[k] = bucket[s + i];
-                lo = min(lo, rec[k].x);
-                hi = max(hi, rec[k].x);
-            }
-        }
-    } else {
-        for (int i = t; i < n; i += TS_THREADS) {
-            const unsigned d = bucket[s + i].x;
-            lo = min(lo, d);
-            hi = max(hi, d);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
-        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
-    }
-    if (lane == 0) { red_lo[wave] = lo; red_hi[wave] = hi; }
-    __syncthreads();
-    lo = min(min(red_lo[0], red_lo[1]), min(red_lo[2], red_lo[3]));
-    hi = max(max(red_hi[0], red_hi[1]), max(red_hi[2], red_hi[3]));
-    const float scale = (float)nbk / ((float)(hi - lo) + 1.0f);
-    auto sub_bucket = [&](unsigned d) -> int {
-        const int v = (int)((float)(d - lo) * scale);     // monotone in d
-        return min(v, nbk - 1);
-    };
-
-    // histogram
-    if constexpr (E > 0) {
-#pragma unroll
-        for (int k = 0; k < E; ++k)
-            if (t + k * TS_THREADS < n) atomicAdd(&boff[sub_bucket(rec[k].x)], 1u);
-    } else {
-        for (int i = t; i < n; i += TS_THREADS) atomicAdd(&boff[sub_bucket(bucket[s + i].x)], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over nbk counters: thread t owns per_thread consecutive counters
-    unsigned sum = 0, occ = 0;
-    for (int k = 0; k < per_thread; ++k) {
-        const unsigned c = boff[t * per_thread + k];
-        sum += c;
-        occ = max(occ, c);
-    }
-    const unsigned incl = (unsigned)sc_wave_incl_scan((int)sum);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) occ = max(occ, (unsigned)__shfl_xor((int)occ, o, 64));
-    if (lane == 63) red_sum[wave] = incl;
-    if (lane == 0) red_occ[wave] = occ;
-    __syncthreads();
-    occ = max(max(red_occ[0], red_occ[1]), max(red_occ[2], red_occ[3]));
-    if (occ > BS_MAX_OCC) {                     // workgroup-uniform
-        if (t == 0) needs_radix[b] = 1;
-        return;
-    }
-    unsigned run = incl - sum;
-#pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) if (w < wave) run += red_sum[w];
-    for (int k = 0; k < per_thread; ++k) {      // counts -> sub-bucket starts (used as running cursors)
-        const unsigned c = boff[t * per_thread + k];
-        boff[t * per_thread + k] = run;
-        run += c;
-    }
-    __syncthreads();
-    // scatter: after this pass boff[j] is the END of sub-bucket j (== start of j+1)
-    if constexpr (E > 0) {
-#pragma unroll
-        for (int k = 0; k < E; ++k) {
-            if (t + k * TS_THREADS < n) {
-                const unsigned slot = atomicAdd(&boff[sub_bucket(rec[k].x)], 1u);
-                B[slot] = ((unsigned long long)rec[k].x << 32) | rec[k].y;
-            }
-        }
-    } else {
-        for (int i = t; i < n; i += TS_THREADS) {
-            const uint2 r = bucket[s + i];
-            const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
-            B[slot] = ((unsigned long long)r.x << 32) | r.y;
-        }
-    }
-    __syncthreads();
-    // rank inside the sub-bucket by (depth bits, flat id) and write the final records
-    if (dbg & 2) return;
-    for (int p = t; p < n; p += TS_THREADS) {
-        const unsigned long long key = B[p];
-        const int j = sub_bucket((unsigned)(key >> 32));
-        const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
-        unsigned r = beg;
-        for (unsigned q = beg; q < end; ++q) r += (B[q] < key) ? 1u : 0u;
-        if (dbg & 1) { if (r == 0xffffffffu) flatten_ids[s] = 0; continue; }
-        if (isect_ids) isect_ids[s + r] = hi_key | (long long)(key >> 32);
-        flatten_ids[s + r] = (int32_t)(unsigned)key;
+        emit_tiles<TS_THREADS>(src, n, sb, g, offsets, 0, 0, tile_bits, table, isect_ids, flatten_ids, 0);
     }
 }
 
 }  // namespace
 
 // ---- host side --------------------------------------------------------------------------------
-// count-phase workspace (must be handed to BOTH calls):
-//   counts[nb] | ccounts[nb] | ccursor[nb] | cstart[nb] (i32) | cmeta[2] (i64) | perm[CN] (i32)
+// count-phase workspace (handed to BOTH calls):
+//   dgrid_t | dgrid_s | chist | ccursor | soffsets | cstart | smeta[2] | cmeta[2] | perm[CN]
 // sort-phase workspace:
-//   cursor[nb] | needs_radix[nb bytes, padded] | records uint2[capacity]
-static inline size_t bin_counts_bytes(int n_buckets) { return sc_align_up((size_t)n_buckets * 4, 256); }
+//   cursor[nsb] | needs_radix[nsb] | records uint2[rec_capacity]
+struct BinLayout {
+    Geo g;
+    int C, nt_cells, ns_cells, nsb, ntb;
+    size_t dgrid_t, dgrid_s, chist, ccursor, soffsets, cstart, smeta, cmeta, perm, total;
+};
 
-struct BinCountLayout { size_t counts, ccounts, ccursor, cstart, cmeta, perm, total; };
-static BinCountLayout bin_count_layout(int64_t CN, int nb) {
-    BinCountLayout L;
-    const size_t cb = bin_counts_bytes(nb);
-    L.counts = 0; L.ccounts = cb; L.ccursor = 2 * cb; L.cstart = 3 * cb; L.cmeta = 4 * cb;
-    L.perm = 4 * cb + 256;
-    L.total = L.perm + sc_align_up((size_t)(CN > 0 ? CN : 0) * 4, 256);
+static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
+    BinLayout L;
+    L.C = C;
+    L.g.tile_width = tile_width; L.g.tile_height = tile_height; L.g.T = tile_width * tile_height;
+    L.g.ss = 1;
+    L.g.stw = (tile_width + 1) >> 1; L.g.sth = (tile_height + 1) >> 1; L.g.ST = L.g.stw * L.g.sth;
+    L.g.N = N;
+    L.ntb = C * L.g.T;
+    L.nsb = C * L.g.ST;
+    L.nt_cells = C * (tile_height + 1) * (tile_width + 1);
+    L.ns_cells = C * (L.g.sth + 1) * (L.g.stw + 1);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += sc_align_up(bytes, 256); return at; };
+    L.dgrid_t = take((size_t)L.nt_cells * 4);
+    L.dgrid_s = take((size_t)L.ns_cells * 4);
+    L.chist = take((size_t)L.nsb * 4);
+    L.ccursor = take((size_t)L.nsb * 4);
+    L.soffsets = take((size_t)L.nsb * 4);
+    L.cstart = take((size_t)L.nsb * 4);
+    L.smeta = take(16);
+    L.cmeta = take(16);
+    L.perm = take((size_t)(CN > 0 ? CN : 0) * 4);
+    L.total = o;
     return L;
+}
+
+static inline size_t count_lds_bytes(const BinLayout& L) {
+    return (size_t)(L.nt_cells + L.ns_cells + L.nsb) * 4;
 }
 
 extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height,
                                                int64_t n_isects) {
     const int64_t nb = (int64_t)C * tile_width * tile_height;
-    if (nb <= 0 || nb > BIN_MAX_BUCKETS) return 256;
-    if (n_isects < 0) return bin_count_layout(CN, (int)nb).total;    // count-phase workspace
-    return 2 * bin_counts_bytes((int)nb) + sc_align_up((size_t)n_isects * 8, 256) + 256;
+    if (nb <= 0 || nb > BIN_MAX_TILES) return 256;
+    const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
+    if (n_isects < 0) return L.total;                                  // count-phase workspace
+    return 2 * sc_align_up((size_t)L.nsb * 4, 256) + sc_align_up((size_t)n_isects * 8, 256) + 256;
 }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N, int tile_size,
@@ -568,36 +697,49 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     if (!meta_dev) return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
     const int64_t nb64 = (int64_t)C * tile_width * tile_height;
-    if (nb64 > BIN_MAX_BUCKETS || CN > 0x7fffffffLL) return SC_EUNSUPPORTED;
-    const int nb = (int)nb64;
+    if (nb64 > BIN_MAX_TILES || CN >= (1LL << 28)) return SC_EUNSUPPORTED;   // ids share a word with the mask
     hipStream_t s = sc_s(stream);
-    if (CN == 0 || nb == 0) {
-        if (nb > 0 && isect_offsets) SC_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)nb * 4, s));
-        return (int)hipMemsetAsync(meta_dev, 0, 2 * sizeof(int64_t), s);
+    if (CN == 0 || nb64 == 0) {
+        if (nb64 > 0 && isect_offsets) SC_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)nb64 * 4, s));
+        return (int)hipMemsetAsync(meta_dev, 0, 4 * sizeof(int64_t), s);
     }
     if (!means2d || !radii || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
-    const BinCountLayout L = bin_count_layout(CN, nb);
+    const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
     if (ws_bytes < L.total) return SC_EWORKSPACE;
+    if (count_lds_bytes(L) > 150 * 1024 || (size_t)L.nt_cells * 4 > 150 * 1024) return SC_EUNSUPPORTED;
     unsigned char* ws = (unsigned char*)count_workspace;
-    unsigned* counts = (unsigned*)(ws + L.counts);
-    unsigned* ccounts = (unsigned*)(ws + L.ccounts);
+    int* dgrid_t = (int*)(ws + L.dgrid_t);
+    int* dgrid_s = (int*)(ws + L.dgrid_s);
+    unsigned* chist = (unsigned*)(ws + L.chist);
     unsigned* ccursor = (unsigned*)(ws + L.ccursor);
+    int32_t* soffsets = (int32_t*)(ws + L.soffsets);
     int32_t* cstart = (int32_t*)(ws + L.cstart);
     int64_t* cmeta = (int64_t*)(ws + L.cmeta);
     int32_t* perm = (int32_t*)(ws + L.perm);
-    SC_HIP(hipMemsetAsync(ws, 0, 3 * bin_counts_bytes(nb), s));        // counts, ccounts, ccursor
+    SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)grid_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        attr_set = true;
+    }
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
-    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, CN, N,
-                       (float)tile_size, tile_width, tile_height, nb, tiles_per_gauss, counts, ccounts);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(BIN_THREADS), count_lds_bytes(L), s, means2d, radii, CN,
+                       L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)counts, nb, isect_offsets,
-                       meta_dev);
+    // tiles: offsets + meta[0] (total intersections), meta[1] (largest tile)
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), (size_t)L.nt_cells * 4, s, (const int*)dgrid_t, C,
+                       tile_width, tile_height, isect_offsets, meta_dev);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)ccounts, nb, cstart, cmeta);
+    // super-tiles: record offsets + meta[2] (total records), meta[3] (largest super-tile)
+    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), (size_t)L.ns_cells * 4, s, (const int*)dgrid_s, C,
+                       L.g.stw, L.g.sth, soffsets, meta_dev + 2);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s,
-                       (const int32_t*)tiles_per_gauss, means2d, radii, CN, N, (float)tile_size, tile_width,
-                       tile_height, nb, (const int32_t*)cstart, ccursor, perm);
+    hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)chist, L.nsb, cstart, cmeta);
+    SC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)L.nsb * 8, s,
+                       (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
+                       (const int32_t*)cstart, ccursor, perm);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
@@ -605,66 +747,66 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
 extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C,
                                  int N, int tile_size, int tile_width, int tile_height,
                                  const int32_t* isect_offsets, const int64_t* meta_dev,
-                                 const void* count_workspace, int64_t capacity, int64_t tile_capacity,
-                                 int64_t* isect_ids, int32_t* flatten_ids, void* workspace,
-                                 size_t ws_bytes, sc_stream_t stream) {
+                                 const void* count_workspace, int64_t capacity, int64_t rec_capacity,
+                                 int64_t super_capacity, int64_t* isect_ids, int32_t* flatten_ids,
+                                 void* workspace, size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0 || capacity < 0 ||
-        tile_capacity < 0)
+        rec_capacity < 0 || super_capacity < 0)
         return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
     const int64_t nb64 = (int64_t)C * tile_width * tile_height;
-    if (nb64 > BIN_MAX_BUCKETS || CN > 0x7fffffffLL || capacity > 0x7fffffffLL) return SC_EUNSUPPORTED;
+    if (nb64 > BIN_MAX_TILES || CN >= (1LL << 28) || capacity > 0x7fffffffLL) return SC_EUNSUPPORTED;
     if (capacity == 0 || CN == 0) return SC_OK;
-    const int nb = (int)nb64;
-    // LDS of one tile-sort workgroup: 16 B per record must fit ~150 KiB
-    if (tile_capacity > 9216) return SC_EUNSUPPORTED;
-    int cap = (int)((tile_capacity + 255) / 256 * 256);
+    // LDS of one super-tile workgroup: 20 B per record (+ table) must fit ~150 KiB
+    if (super_capacity > 7168) return SC_EUNSUPPORTED;
+    int cap = (int)((super_capacity + 255) / 256 * 256);
     if (cap < 256) cap = 256;
     if (!means2d || !radii || !depths || !isect_offsets || !meta_dev || !count_workspace || !flatten_ids ||
         !workspace)
         return SC_EINVAL;
-    if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, capacity)) return SC_EWORKSPACE;
+    if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, rec_capacity)) return SC_EWORKSPACE;
     hipStream_t s = sc_s(stream);
-    const BinCountLayout L = bin_count_layout(CN, nb);
+    const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
     const unsigned char* cws = (const unsigned char*)count_workspace;
+    const int32_t* soffsets = (const int32_t*)(cws + L.soffsets);
     const int64_t* cmeta = (const int64_t*)(cws + L.cmeta);
     const int32_t* perm = (const int32_t*)(cws + L.perm);
     unsigned char* ws = (unsigned char*)workspace;
+    const size_t nsb_bytes = sc_align_up((size_t)L.nsb * 4, 256);
     unsigned* cursor = (unsigned*)ws;
-    unsigned char* needs_radix = ws + bin_counts_bytes(nb);
-    uint2* bucket = (uint2*)(ws + 2 * bin_counts_bytes(nb));
-    SC_HIP(hipMemsetAsync(ws, 0, 2 * bin_counts_bytes(nb), s));   // cursor + needs_radix flags
-    const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)nb * 8, s, means2d, radii, depths,
-                       perm, cmeta, N, (float)tile_size, tile_width, tile_height, nb, isect_offsets, meta_dev,
-                       capacity, (int64_t)cap, cursor, bucket, g_sc_debug[0]);
+    unsigned char* needs_radix = ws + nsb_bytes;
+    uint2* records = (uint2*)(ws + 2 * nsb_bytes);
+    SC_HIP(hipMemsetAsync(ws, 0, 2 * nsb_bytes, s));   // cursor + needs_radix flags
+    const unsigned grid = (unsigned)((CN + SCAT_GPB - 1) / SCAT_GPB);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(SCAT_THREADS), (size_t)L.nsb * 8, s, means2d, radii,
+                       depths, perm, cmeta, L.g, (float)tile_size, L.nsb, soffsets, meta_dev, capacity,
+                       rec_capacity, (int64_t)cap, cursor, records, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
-    const int tiles_per_cam = tile_width * tile_height;
-    const int tile_bits = sc_bits_for(tiles_per_cam);
+    const int tile_bits = sc_bits_for(L.g.T);
     const int id_bits = sc_bits_for(CN > 1 ? CN - 1 : 1);
+    // sub-buckets per thread: ~1 per record (keeps two workgroups resident per CU), rounded up to
+    // an ODD count (bank-conflict-free scan)
+    int per_thread = (cap + SS_THREADS - 1) / SS_THREADS;
+    per_thread |= 1;
+    const int nbk = SS_THREADS * per_thread;
+    const size_t table_bytes = (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64;
+    const size_t lds_sort = (size_t)cap * 16 + (size_t)((nbk + 2) & ~1) * 4 + table_bytes;
+    const size_t table_radix = (size_t)((cap + TS_THREADS - 1) / TS_THREADS + 1) * TS_WAVES * 8 + 64;
+    const size_t lds_radix = (size_t)cap * 16 + table_radix;
+    if (lds_sort > 156 * 1024) return SC_EUNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        SC_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   152 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel<0>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)tile_bucket_sort_kernel<12>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)super_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)super_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
-    // common path: interpolation sort; it flags the (rare) tiles it leaves to the radix kernel
-#define SC_LAUNCH_BS(EV)                                                                                      \
-    hipLaunchKernelGGL(tile_bucket_sort_kernel<EV>, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16 + 16, s,          \
-                       (const uint2*)bucket, isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, cap, \
-                       needs_radix, isect_ids, flatten_ids, g_sc_debug[2])
-    if (cap <= 4 * TS_THREADS) SC_LAUNCH_BS(4);
-    else if (cap <= 8 * TS_THREADS) SC_LAUNCH_BS(8);
-    else if (cap <= 12 * TS_THREADS) SC_LAUNCH_BS(12);
-    else SC_LAUNCH_BS(0);
-#undef SC_LAUNCH_BS
+    hipLaunchKernelGGL(super_sort_kernel, dim3(L.nsb), dim3(SS_THREADS), lds_sort, s, (const uint2*)records, soffsets,
+                       L.nsb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, cap, per_thread,
+                       needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
     SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(nb), dim3(TS_THREADS), (size_t)cap * 16, s, (const uint2*)bucket,
-                       isect_offsets, nb, meta_dev, capacity, tiles_per_cam, tile_bits, id_bits, cap,
+    const int rgrid = L.nsb < 512 ? L.nsb : 512;
+    hipLaunchKernelGGL(super_radix_kernel, dim3(rgrid), dim3(TS_THREADS), lds_radix, s, (const uint2*)records, soffsets,
+                       L.nsb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, id_bits, cap,
                        (const unsigned char*)needs_radix, isect_ids, flatten_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;

@@ -1,4 +1,4 @@
-// Constants shared by the rasterizer kernels.
+// Constants and the pinned pair arithmetic shared by the rasterizer kernels.
 #pragma once
 #include "sc_common.h"
 
@@ -6,24 +6,44 @@
 #define SC_ALPHA_MAX 0.999f
 #define SC_T_EPS 1e-4f
 #define SC_MAX_CDIM 32
+#define SC_LOG2E 1.4426950408889634f
+#define SC_HALF_LOG2E 0.7213475204444817f
 
-// alpha-test threshold in the exponent domain:  o * exp(-sigma) >= 1/255  <=>  sigma <= ln(255 o)
-__device__ __forceinline__ float sc_fast_exp(float x) { return __expf(x); }
+// The pair evaluation.  The blend loop is VALU-bound (rocprof: the VALU is busy ~80 % of the
+// kernel), so the per-pixel work is folded as far as the algebra allows:
+//     alpha = min(0.999, op * exp(-sigma)),  sigma = 0.5 (a dx^2 + c dy^2) + b dx dy
+//           = min(0.999, exp2(log2(op) - sigma2)),
+//     sigma2 = sigma * log2(e) = (A2 dx + B2 dy) dx + (C2 dy) dy,   A2 = a log2(e)/2, B2 = b log2(e),
+//                                                                 C2 = c log2(e)/2
+// A2/B2/C2/log2(op) are computed once per staged splat; (B2 dy) and (C2 dy) dy once per lane row.
+// Every rounding point is pinned with explicit mul/fma intrinsics, so every forward variant and the
+// backward replay compute bit-identical sigma2 / alpha / transmittance and always take the same
+// skip / terminate decisions (no compiler-chosen contraction).  Relative to the literal formula
+// alpha moves by ~2e-6 (relative); pixels stay within the 1e-4 bar of the parity tests.
+// Opacity <= 0 (or NaN) gives alpha = 0 / NaN and the splat is skipped (alpha >= 1/255 is false).
+struct ScSplat { float mx, my, A2, B2, C2, lop; };
 
-// The pair evaluation, with the rounding points pinned by explicit mul/fma intrinsics: every
-// forward variant and the backward replay compute bit-identical sigma / alpha / transmittance,
-// so their skip / terminate decisions always agree (no compiler-chosen contraction).
-//   sigma = 0.5*(a dx^2 + c dy^2) + b dx dy          
-__device__ __forceinline__ float sc_sigma(float ca, float cb, float cc, float dx, float dy) {
-    const float q = __fmaf_rn(__fmul_rn(cc, dy), dy, __fmul_rn(__fmul_rn(ca, dx), dx));
-    return __fmaf_rn(__fmul_rn(cb, dx), dy, __fmul_rn(0.5f, q));
+__device__ __forceinline__ ScSplat sc_prescale(float mx, float my, float a, float b, float c, float op) {
+    ScSplat s;
+    s.mx = mx; s.my = my;
+    s.A2 = __fmul_rn(a, SC_HALF_LOG2E);
+    s.B2 = __fmul_rn(b, SC_LOG2E);
+    s.C2 = __fmul_rn(c, SC_HALF_LOG2E);
+    s.lop = __log2f(op);
+    return s;
 }
-__device__ __forceinline__ float sc_vis(float sigma) { return sc_fast_exp(-sigma); }
-__device__ __forceinline__ float sc_alpha(float op, float vis) {
-    return fminf(SC_ALPHA_MAX, __fmul_rn(op, vis));
+// per-lane-row terms, shared by the pixels of one row
+__device__ __forceinline__ float sc_row_b(float B2, float dy) { return __fmul_rn(B2, dy); }
+__device__ __forceinline__ float sc_row_q(float C2, float dy) { return __fmul_rn(__fmul_rn(C2, dy), dy); }
+__device__ __forceinline__ float sc_sigma2(float A2, float bdy, float q, float dx) {
+    return __fmaf_rn(__fmaf_rn(A2, dx, bdy), dx, q);
 }
-__device__ __forceinline__ float sc_next_T(float T, float alpha) {
-    return __fmul_rn(T, __fsub_rn(1.0f, alpha));
+__device__ __forceinline__ float sc_alpha2(float lop, float sigma2) {
+    return fminf(SC_ALPHA_MAX, __builtin_amdgcn_exp2f(__fsub_rn(lop, sigma2)));
 }
+__device__ __forceinline__ bool sc_valid(float sigma2, float alpha) {
+    return !(sigma2 < 0.f) && (alpha >= SC_ALPHA_MIN);
+}
+__device__ __forceinline__ float sc_next_T(float T, float alpha) { return __fmaf_rn(-alpha, T, T); }
 
-extern int g_sc_raster_fwd_variant;  // 0 = reference-shaped, 1 = culled (default)
+extern int g_sc_raster_fwd_variant;  // see include/street_crafter_amd.h (sc_set_option "raster_fwd")

@@ -210,13 +210,14 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_PINNED_META = {}      # device index -> pinned int64[4] used for the one D2H read per frame
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
                      tiles_per_gauss, total_dev, st):
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
-    meta_dev = torch.empty(2, dtype=torch.int64, device=dev)
+    meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
     ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev), _p(ws0),
@@ -224,18 +225,20 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
     _lib.check(rc, "sc_isect_bin_count")
-    meta_host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    meta_host = _PINNED_META.get(dev.index)
+    if meta_host is None:
+        meta_host = _PINNED_META[dev.index] = torch.empty(4, dtype=torch.int64, pin_memory=True)
     meta_host.copy_(meta_dev, non_blocking=True)
     ready = torch.cuda.Event()
     ready.record()
 
-    def launch(capacity, tile_capacity):
+    def launch(capacity, rec_capacity, super_capacity):
         ids = torch.empty(capacity, dtype=torch.int64, device=dev)
         fids = torch.empty(capacity, dtype=torch.int32, device=dev)
-        ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, capacity), dev)
+        ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, rec_capacity), dev)
         r = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
-                                  int(tile_height), _p(offsets), _p(meta_dev), _p(ws0), capacity, tile_capacity,
-                                  _p(ids), _p(fids), _p(ws), ws.numel(), st)
+                                  int(tile_height), _p(offsets), _p(meta_dev), _p(ws0), capacity, rec_capacity,
+                                  super_capacity, _p(ids), _p(fids), _p(ws), ws.numel(), st)
         return r, ids, fids
 
     key = (dev.index, C, N, int(tile_size), int(tile_width), int(tile_height))
@@ -248,14 +251,15 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         elif rc != 0:
             _lib.check(rc, "sc_isect_bin_sort")
     ready.synchronize()        # the one D2H read of a frame (sizes the outputs); GPU already has work
-    n_isects, max_per_tile = int(meta_host[0]), int(meta_host[1])
-    if rc is None or n_isects > pred[0] or max_per_tile > pred[1]:
-        rc, ids, fids = launch(n_isects, max_per_tile)
+    n_isects, _, n_records, max_super = (int(v) for v in meta_host.tolist())
+    if rc is None or n_isects > pred[0] or n_records > pred[1] or max_super > pred[2]:
+        rc, ids, fids = launch(n_isects, n_records, max_super)
         if rc == -3:
             return None
         _lib.check(rc, "sc_isect_bin_sort")
     # next call: 12.5 % head-room over what this frame needed
-    _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, min(9216, max_per_tile + max_per_tile // 8 + 64))
+    _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, n_records + n_records // 8 + 4096,
+                            min(7168, max_super + max_super // 8 + 64))
     isect_ids, flatten_ids = ids[:n_isects], fids[:n_isects]
     # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
     # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
