@@ -797,7 +797,8 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)super_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)super_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        // (this kernel also has ~4 KiB of static LDS: stay below 160 KiB in total)
+        SC_HIP(hipFuncSetAttribute((const void*)super_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(super_sort_kernel, dim3(L.nsb), dim3(SS_THREADS), lds_sort, s, (const uint2*)records, soffsets,

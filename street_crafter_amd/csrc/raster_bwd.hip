@@ -92,10 +92,13 @@ __global__ void raster_bwd_kernel(
                 const float2 bc = bc_s[t];
                 ca = a.w; cb = bc.x; cc = bc.y; opac = a.z;
                 dx = a.x - px; dy = a.y - py;
-                const float sigma = sc_sigma(ca, cb, cc, dx, dy);
-                vis = sc_vis(sigma);
-                alpha = sc_alpha(opac, vis);
-                if (sigma < 0.f || alpha < SC_ALPHA_MIN) valid = false;
+                // the skip decision uses the forward's exact arithmetic (raster_common.h) ...
+                const ScSplat sp = sc_prescale(a.x, a.y, ca, cb, cc, opac);
+                const float sigma2 = sc_sigma2(sp.A2, sc_row_b(sp.B2, dy), sc_row_q(sp.C2, dy), dx);
+                alpha = sc_alpha2(sp.lop, sigma2);
+                if (!sc_valid(sigma2, alpha)) valid = false;
+                // ... the gradient formulas need exp(-sigma) itself
+                vis = __builtin_amdgcn_exp2f(-sigma2);
             }
             if (!__any(valid)) continue;
             float v_rgb[ND];

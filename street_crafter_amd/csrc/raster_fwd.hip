@@ -81,8 +81,9 @@ __global__ void raster_fwd_ref_kernel(
             id_s[tr] = g;
             const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
             const float* cn = conics + (int64_t)g * 3;
-            xyoa_s[tr] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
-            bc_s[tr] = make_float2(cn[1], cn[2]);
+            const ScSplat sp = sc_prescale(xy.x, xy.y, cn[0], cn[1], cn[2], opacities[g]);
+            xyoa_s[tr] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+            bc_s[tr] = make_float2(sp.B2, sp.C2);
         }
         __syncthreads();
         const int bsz = min(B, range_end - batch_start);
@@ -90,9 +91,9 @@ __global__ void raster_fwd_ref_kernel(
             const float4 a = xyoa_s[t];
             const float2 bc = bc_s[t];
             const float dx = a.x - px, dy = a.y - py;
-            const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
-            const float alpha = sc_alpha(a.z, sc_vis(sigma));
-            if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
+            const float sigma = sc_sigma2(a.w, sc_row_b(bc.x, dy), sc_row_q(bc.y, dy), dx);
+            const float alpha = sc_alpha2(a.z, sigma);
+            if (!sc_valid(sigma, alpha)) continue;
             const float next_T = sc_next_T(T, alpha);
             if (next_T <= SC_T_EPS) { done = true; break; }
             const float vis = __fmul_rn(alpha, T);
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
             const float ca = cn[0], cb = cn[1], cc = cn[2];
             const float op = opacities[g];
             keep = !splat_misses_rect(ca, cb, cc, op, rx0 - xy.x, rx1 - xy.x, ry0 - xy.y, ry1 - xy.y);
-            v0 = make_float4(xy.x, xy.y, op, ca);
-            v1 = make_float4(cb, cc, __int_as_float(idx), 0.f);
+            const ScSplat sp = sc_prescale(xy.x, xy.y, ca, cb, cc, op);
+            v0 = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+            v1 = make_float4(sp.B2, sp.C2, __int_as_float(idx), 0.f);
             if (keep) {
                 const float* c = colors + (int64_t)g * CDIM;
                 v2 = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
@@ -255,9 +257,9 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
             const float4 a = xyoa_s[t];
             const float4 bc = bck_s[t];
             const float dx = a.x - px, dy = a.y - py;
-            const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
-            const float alpha = sc_alpha(a.z, sc_vis(sigma));
-            if (sigma < 0.f || alpha < SC_ALPHA_MIN) continue;
+            const float sigma = sc_sigma2(a.w, sc_row_b(bc.x, dy), sc_row_q(bc.y, dy), dx);
+            const float alpha = sc_alpha2(a.z, sigma);
+            if (!sc_valid(sigma, alpha)) continue;
             const float next_T = sc_next_T(T, alpha);
             if (next_T <= SC_T_EPS) { done = true; break; }
             const float vis = __fmul_rn(alpha, T);
@@ -400,8 +402,9 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
         }
         if (keep) {
             const int slot = base + __popcll(m & sc_lanemask_lt());
-            xyoa_s[slot] = make_float4(p_xy.x, p_xy.y, p_op, p_a);
-            bck_s[slot] = make_float4(p_b, p_c, __int_as_float(batch_start + tr), 0.f);
+            const ScSplat sp = sc_prescale(p_xy.x, p_xy.y, p_a, p_b, p_c, p_op);
+            xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+            bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(batch_start + tr), 0.f);
             col_s[slot] = p_col;
         }
         __syncthreads();
@@ -427,9 +430,9 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
             for (int t = 0; t < bsz; ++t) {
                 const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
                 const float dx = a.x - px, dy = a.y - py;
-                const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
-                const float alpha = sc_alpha(a.z, sc_vis(sigma));
-                const bool valid = !done && !(sigma < 0.f) && !(alpha < SC_ALPHA_MIN);
+                const float sigma = sc_sigma2(a.w, sc_row_b(bc.x, dy), sc_row_q(bc.y, dy), dx);
+                const float alpha = sc_alpha2(a.z, sigma);
+                const bool valid = !done && sc_valid(sigma, alpha);
                 const float next_T = sc_next_T(T, alpha);
                 const bool term = valid && (next_T <= SC_T_EPS);
                 done = done || term;
@@ -597,8 +600,9 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int slot = bsz + __popcll(m & sc_lanemask_lt());
-                xyoa_s[slot] = make_float4(p_xy[j].x, p_xy[j].y, p_op[j], p_a[j]);
-                bck_s[slot] = make_float4(p_b[j], p_c[j], __int_as_float(batch_start + j * 64 + lane), 0.f);
+                const ScSplat sp = sc_prescale(p_xy[j].x, p_xy[j].y, p_a[j], p_b[j], p_c[j], p_op[j]);
+                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+                bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(batch_start + j * 64 + lane), 0.f);
                 col_s[slot] = p_col[j];
             }
             bsz += __popcll(m);
@@ -619,13 +623,14 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             for (int t = 0; t < bsz; ++t) {
                 const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
                 const float dy = a.y - py;
+                const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the 4 pixels
                 const int sidx = __float_as_int(bc.z);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float dx = a.x - pxf[k];
-                    const float sigma = sc_sigma(a.w, bc.x, bc.y, dx, dy);
-                    const float alpha = sc_alpha(a.z, sc_vis(sigma));
-                    const bool valid = !done[k] && !(sigma < 0.f) && !(alpha < SC_ALPHA_MIN);
+                    const float sigma = sc_sigma2(a.w, bdy, qdy, dx);
+                    const float alpha = sc_alpha2(a.z, sigma);
+                    const bool valid = !done[k] && sc_valid(sigma, alpha);
                     const float next_T = sc_next_T(T[k], alpha);
                     const bool term = valid && (next_T <= SC_T_EPS);
                     done[k] = done[k] || term;
