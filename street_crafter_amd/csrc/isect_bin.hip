@@ -38,8 +38,6 @@ constexpr int BIN_THREADS = 1024;
 constexpr int BIN_GPT = 4;                       // gaussians per thread in the count / centre passes
 constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
 constexpr int SCAT_THREADS = 256;
-constexpr int SCAT_GPT = 4;
-constexpr int SCAT_GPB = SCAT_THREADS * SCAT_GPT;
 constexpr int BIN_MAX_TILES = 16384;             // C * tile_width * tile_height handled by this path
 constexpr int BIN_BIG = 64;                      // rectangles larger than this are walked by a whole wave
 constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
@@ -288,6 +286,8 @@ __device__ __forceinline__ void walk_super(const Rect& r, bool live, int cam_bas
     }
 }
 
+// GPT = Gaussians per thread (fewer -> more, lighter workgroups: the pass is latency-bound)
+template <int SCAT_GPT>
 __global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii,
     const float* __restrict__ depths, const int32_t* __restrict__ perm,
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     const int64_t M = n_visible[0];
+    constexpr int SCAT_GPB = SCAT_THREADS * SCAT_GPT;
     const int64_t base = (int64_t)blockIdx.x * SCAT_GPB;
     if (base >= M) return;
     unsigned* hist = lds;                  // [n_sbuckets] counts, then running local cursors
@@ -777,10 +778,17 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     unsigned char* needs_radix = ws + nsb_bytes;
     uint2* records = (uint2*)(ws + 2 * nsb_bytes);
     SC_HIP(hipMemsetAsync(ws, 0, 2 * nsb_bytes, s));   // cursor + needs_radix flags
-    const unsigned grid = (unsigned)((CN + SCAT_GPB - 1) / SCAT_GPB);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(grid), dim3(SCAT_THREADS), (size_t)L.nsb * 8, s, means2d, radii,
-                       depths, perm, cmeta, L.g, (float)tile_size, L.nsb, soffsets, meta_dev, capacity,
-                       rec_capacity, (int64_t)cap, cursor, records, g_sc_debug[0]);
+#define SC_LAUNCH_SCATTER(GPT)                                                                               \
+    hipLaunchKernelGGL(bin_scatter_kernel<GPT>, dim3((unsigned)((CN + SCAT_THREADS * GPT - 1) / (SCAT_THREADS * GPT))), \
+                       dim3(SCAT_THREADS), (size_t)L.nsb * 8, s, means2d, radii, depths, perm, cmeta, L.g,          \
+                       (float)tile_size, L.nsb, soffsets, meta_dev, capacity, rec_capacity, (int64_t)cap, cursor,   \
+                       records, g_sc_debug[0])
+    switch (g_sc_debug[3]) {            // tuning knob: Gaussians per thread (default 2)
+        case 1: SC_LAUNCH_SCATTER(1); break;
+        case 4: SC_LAUNCH_SCATTER(4); break;
+        default: SC_LAUNCH_SCATTER(2); break;
+    }
+#undef SC_LAUNCH_SCATTER
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
     const int id_bits = sc_bits_for(CN > 1 ? CN - 1 : 1);

@@ -23,6 +23,8 @@ cam = make_camera().to(dev)
 
 CONFIGS = [
     ("baseline", {}),
+    ("scatter: 1 gaussian/thread", {"debug3": 1}),
+    ("scatter: 4 gaussians/thread", {"debug3": 4}),
     ("scatter: no record store", {"debug0": 1}),
     ("scatter: no pass 2", {"debug0": 2}),
     ("scatter: no reservation atomics", {"debug0": 4}),

@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline"
 i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
          "FETCH_SIZE" "WRITE_SIZE" \
@@ -14,3 +14,4 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pass$i" -- $CMD > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 tools/summarize_pmc.py "$OUT" "$OUT/summary.md"
+python3 tools/make_traffic_json.py "$OUT" "$OUT/pmc_traffic.json" n1000000 10
