@@ -160,17 +160,30 @@ __global__ __launch_bounds__(1024) void grid_scan_kernel(const int* __restrict__
     const int W = gw + 1, H = gh + 1, ncell = C * H * W;
     for (int i = t; i < ncell; i += 1024) grid[i] = dgrid[i];
     __syncthreads();
-    for (int r = t; r < C * H; r += 1024) {          // prefix along x
+    const int lane = sc_lane(), wave = t >> 6;
+    for (int r = wave; r < C * H; r += 16) {         // prefix along x: one wave per row, 64 cells a step
         int* row = grid + r * W;
-        int run = 0;
-        for (int x = 0; x < W; ++x) { run += row[x]; row[x] = run; }
+        int carry = 0;
+        for (int x0 = 0; x0 < W; x0 += 64) {
+            const int x = x0 + lane;
+            const int v = x < W ? row[x] : 0;
+            const int incl = sc_wave_incl_scan(v) + carry;
+            if (x < W) row[x] = incl;
+            carry = __shfl(incl, 63, 64);
+        }
     }
     __syncthreads();
-    for (int c = t; c < C * W; c += 1024) {          // prefix along y
+    for (int c = wave; c < C * W; c += 16) {         // prefix along y: one wave per column
         const int cam = c / W, x = c - cam * W;
         int* col = grid + cam * H * W + x;
-        int run = 0;
-        for (int y = 0; y < H; ++y) { run += col[y * W]; col[y * W] = run; }
+        int carry = 0;
+        for (int y0 = 0; y0 < H; y0 += 64) {
+            const int y = y0 + lane;
+            const int v = y < H ? col[y * W] : 0;
+            const int incl = sc_wave_incl_scan(v) + carry;
+            if (y < H) col[y * W] = incl;
+            carry = __shfl(incl, 63, 64);
+        }
     }
     __syncthreads();
     const int n = C * gh * gw;
@@ -390,17 +403,20 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     __syncthreads();
     // tile bases
     long long hi_key[4];
-    int tbase[4];
+    int tbase[4], tend[4];
     bool tok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int tx = (sx << g.ss) + (k & 1), ty = (sy << g.ss) + (k >> 1);
         tok[k] = (k < ntile) && tx < g.tile_width && ty < g.tile_height;
         const int tile = ty * g.tile_width + tx;
-        tbase[k] = tok[k] ? offsets[cam * g.T + tile] : 0;
+        const int tflat = cam * g.T + tile;
+        tbase[k] = tok[k] ? offsets[tflat] : 0;
+        // end of this tile's list: a write is dropped rather than allowed past it, so that records
+        // whose masks disagree with the counts (corrupt input, diagnostic skips) cannot go out of bounds
+        tend[k] = tok[k] ? ((tflat + 1 < n_tiles_total) ? offsets[tflat + 1] : (int)n_isects) : 0;
         hi_key[k] = ((long long)cam << (32 + tile_bits)) | ((long long)tile << 32);
     }
-    (void)n_tiles_total; (void)n_isects;
     if (dbg & 1) return;
     for (int r = 0; r < rounds; ++r) {
         const int i = r * THREADS + t;
@@ -412,8 +428,10 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
             const unsigned long long bal = __ballot((m >> k) & 1u);
             if (((m >> k) & 1u) && tok[k]) {
                 const int pos = tbase[k] + (int)((base >> (16 * k)) & 0xffffu) + __popcll(bal & sc_lanemask_lt());
-                if (isect_ids) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
-                flatten_ids[pos] = (int32_t)((unsigned)key & ID_MASK);
+                if (pos < tend[k]) {
+                    if (isect_ids) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
+                    flatten_ids[pos] = (int32_t)((unsigned)key & ID_MASK);
+                }
             }
         }
     }
@@ -426,8 +444,8 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
 constexpr int BS_MAX_OCC = 48;
 
 __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
-    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, Geo g,
-    const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
+    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
+    Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int tile_bits, int cap, int per_thread, unsigned char* __restrict__ needs_radix,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -520,7 +538,7 @@ __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
         S[r] = key;
     }
     __syncthreads();
-    emit_tiles<SS_THREADS>(S, n, sb, g, offsets, 0, 0, tile_bits, table, isect_ids, flatten_ids, dbg);
+    emit_tiles<SS_THREADS>(S, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, dbg);
 }
 
 // ---- radix fallback for flagged super-tiles --------------------------------------------------------------
@@ -582,8 +600,8 @@ __device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ s
 // Persistent-style grid: every workgroup strides over the super-tiles and sorts only the flagged
 // ones (normally none: the launch then costs a few hundred flag reads).
 __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
-    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, Geo g,
-    const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
+    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
+    Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int tile_bits, int id_bits, int cap, const unsigned char* __restrict__ needs_radix,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
             unsigned long long* tmp = src; src = dst; dst = tmp;
             done += bits;
         }
-        emit_tiles<TS_THREADS>(src, n, sb, g, offsets, 0, 0, tile_bits, table, isect_ids, flatten_ids, 0);
+        emit_tiles<TS_THREADS>(src, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, 0);
     }
 }
 
@@ -810,12 +828,12 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
         attr_set = true;
     }
     hipLaunchKernelGGL(super_sort_kernel, dim3(L.nsb), dim3(SS_THREADS), lds_sort, s, (const uint2*)records, soffsets,
-                       L.nsb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, cap, per_thread,
+                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, cap, per_thread,
                        needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
     SC_LAUNCH_CHECK();
     const int rgrid = L.nsb < 512 ? L.nsb : 512;
     hipLaunchKernelGGL(super_radix_kernel, dim3(rgrid), dim3(TS_THREADS), lds_radix, s, (const uint2*)records, soffsets,
-                       L.nsb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, id_bits, cap,
+                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, id_bits, cap,
                        (const unsigned char*)needs_radix, isect_ids, flatten_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;

@@ -74,13 +74,20 @@ __global__ void raster_bwd_kernel(
         const int bsz = min(B, batch_end + 1 - range_start);
         const int idx = batch_end - tr;
         if (idx >= range_start) {
-            const int g = flatten_ids[idx];
-            id_s[tr] = g;
-            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-            const float* cn = conics + (int64_t)g * 3;
-            xyoa_s[tr] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
-            bc_s[tr] = make_float2(cn[1], cn[2]);
-            for (int d = 0; d < D; ++d) rgb_s[tr * D + d] = colors[(int64_t)g * D + d];
+            const int g = sc_safe_id(flatten_ids[idx], N);
+            if (g >= 0) {
+                id_s[tr] = g;
+                const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+                const float* cn = conics + (int64_t)g * 3;
+                xyoa_s[tr] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
+                bc_s[tr] = make_float2(cn[1], cn[2]);
+                for (int d = 0; d < D; ++d) rgb_s[tr * D + d] = colors[(int64_t)g * D + d];
+            } else {                                   // dead entry: opacity 0 -> alpha 0 -> skipped
+                id_s[tr] = 0;
+                xyoa_s[tr] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bc_s[tr] = make_float2(0.f, 0.f);
+                for (int d = 0; d < D; ++d) rgb_s[tr * D + d] = 0.f;
+            }
         }
         __syncthreads();
         for (int t = max(0, batch_end - wave_bin_final); t < bsz; ++t) {
@@ -185,7 +192,7 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
     const size_t shmem = B * 40 + B * D * 4;
 #define SC_LAUNCH_BWD(CD)                                                                              \
     hipLaunchKernelGGL(raster_bwd_kernel<CD>, grid, block, shmem, sc_s(stream), means2d, conics, colors,   \
-                       opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,     \
+                       opacities, backgrounds, tile_masks, C * N, D, width, height, tile_size, tile_width, \
                        tile_height, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,    \
                        v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors,     \
                        v_opacities)

@@ -46,4 +46,10 @@ __device__ __forceinline__ bool sc_valid(float sigma2, float alpha) {
 }
 __device__ __forceinline__ float sc_next_T(float T, float alpha) { return __fmaf_rn(-alpha, T, T); }
 
+// flatten_ids come from the caller (or, in diagnostic runs, from skipped passes): an out-of-range id
+// must never become an out-of-bounds gather.  Returns -1 for ids outside [0, n_splats).
+__device__ __forceinline__ int sc_safe_id(int g, int n_splats) {
+    return ((unsigned)g < (unsigned)n_splats) ? g : -1;
+}
+
 extern int g_sc_raster_fwd_variant;  // see include/street_crafter_amd.h (sc_set_option "raster_fwd")

@@ -77,13 +77,19 @@ __global__ void raster_fwd_ref_kernel(
         const int batch_start = range_start + B * b;
         const int idx = batch_start + tr;
         if (idx < range_end) {
-            const int g = flatten_ids[idx];
-            id_s[tr] = g;
-            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-            const float* cn = conics + (int64_t)g * 3;
-            const ScSplat sp = sc_prescale(xy.x, xy.y, cn[0], cn[1], cn[2], opacities[g]);
-            xyoa_s[tr] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
-            bc_s[tr] = make_float2(sp.B2, sp.C2);
+            const int g = sc_safe_id(flatten_ids[idx], N);
+            if (g >= 0) {
+                id_s[tr] = g;
+                const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+                const float* cn = conics + (int64_t)g * 3;
+                const ScSplat sp = sc_prescale(xy.x, xy.y, cn[0], cn[1], cn[2], opacities[g]);
+                xyoa_s[tr] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+                bc_s[tr] = make_float2(sp.B2, sp.C2);
+            } else {                                   // dead entry: alpha = exp2(-inf) = 0 -> skipped
+                id_s[tr] = 0;
+                xyoa_s[tr] = make_float4(0.f, 0.f, -INFINITY, 0.f);
+                bc_s[tr] = make_float2(0.f, 0.f);
+            }
         }
         __syncthreads();
         const int bsz = min(B, range_end - batch_start);
@@ -219,8 +225,8 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
         // ---- stage + cull -------------------------------------------------------------------
         bool keep = false;
         float4 v0, v1, v2;
-        if (idx < range_end) {
-            const int g = flatten_ids[idx];
+        const int g = (idx < range_end) ? sc_safe_id(flatten_ids[idx], N) : -1;
+        if (g >= 0) {
             const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
             const float* cn = conics + (int64_t)g * 3;
             const float ca = cn[0], cb = cn[1], cc = cn[2];
@@ -369,8 +375,8 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
     int g_next = -1;
     {
         const int idx0 = range_start + tr;
-        if (idx0 < range_end) {
-            const int g = flatten_ids[idx0];
+        const int g = (idx0 < range_end) ? sc_safe_id(flatten_ids[idx0], N) : -1;
+        if (g >= 0) {
             p_xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
             const float* cn = conics + (int64_t)g * 3;
             p_a = cn[0]; p_b = cn[1]; p_c = cn[2];
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
             p_live = true;
         }
         const int idx1 = idx0 + B;
-        if (idx1 < range_end) g_next = flatten_ids[idx1];
+        if (idx1 < range_end) g_next = sc_safe_id(flatten_ids[idx1], N);
     }
 
     for (int b = 0; b < num_batches; ++b) {
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
                 p_col = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
             }
             const int idx2 = batch_start + 2 * B + tr;
-            g_next = (idx2 < range_end) ? flatten_ids[idx2] : -1;
+            g_next = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
         }
         // ---- blend batch b ---------------------------------------------------------------------------
         if (dbg & 1) bsz = 0;
@@ -580,9 +586,13 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
         p_xy[j] = make_float2(0.f, 0.f);
         p_a[j] = p_b[j] = p_c[j] = p_op[j] = 0.f;
         p_col[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p_live[j]) load_splat(flatten_ids[idx0], j);
+        if (p_live[j]) {
+            const int g = sc_safe_id(flatten_ids[idx0], N);
+            p_live[j] = g >= 0;
+            if (p_live[j]) load_splat(g, j);
+        }
         const int idx1 = idx0 + B;
-        g_next[j] = (idx1 < range_end) ? flatten_ids[idx1] : -1;
+        g_next[j] = (idx1 < range_end) ? sc_safe_id(flatten_ids[idx1], N) : -1;
     }
 
     for (int b = 0; b < num_batches; ++b) {
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             p_live[j] = g_next[j] >= 0;
             if (p_live[j]) load_splat(g_next[j], j);
             const int idx2 = batch_start + 2 * B + j * 64 + lane;
-            g_next[j] = (idx2 < range_end) ? flatten_ids[idx2] : -1;
+            g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
         }
         // ---- blend ---------------------------------------------------------------------------------
         if (dbg & 1) bsz = 0;
@@ -710,6 +720,8 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return SC_EINVAL;
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     dim3 grid(tile_width, tile_height, C);
+    if ((int64_t)C * N > 0x7fffffffLL) return SC_EINVAL;
+    const int NS = C * N;                 // kernels bound-check flatten ids against C*N
     const int variant = g_sc_raster_fwd_variant;
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         const int total_tiles = C * tile_width * tile_height;
@@ -720,7 +732,7 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
         float4* recs = packed ? (float4*)workspace : nullptr;
 #define SC_LAUNCH_WAVE(CD, PK)                                                                                  \
     hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
-                       conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, N, width, height,  \
+                       conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, NS, width, height,  \
                        tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,            \
                        render_colors, render_alphas, last_ids, g_sc_debug[1])
         if (packed) {
@@ -746,12 +758,12 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
         const int total_tiles = C * tile_width * tile_height;
         if (D == 4)
             hipLaunchKernelGGL(raster_fwd_v2_kernel<4>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
                                tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
                                render_colors, render_alphas, last_ids, g_sc_debug[1]);
         else
             hipLaunchKernelGGL(raster_fwd_v2_kernel<3>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
                                tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
                                render_colors, render_alphas, last_ids, g_sc_debug[1]);
         SC_LAUNCH_CHECK();
@@ -760,12 +772,12 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if (variant >= 1 && tile_size == 16 && (D == 3 || D == 4)) {
         if (D == 4)
             hipLaunchKernelGGL(raster_fwd_cull_kernel<4>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
-                               colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
                                tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
                                render_alphas, last_ids, g_sc_debug[1]);
         else
             hipLaunchKernelGGL(raster_fwd_cull_kernel<3>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
-                               colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                               colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
                                tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
                                render_alphas, last_ids, g_sc_debug[1]);
         SC_LAUNCH_CHECK();
@@ -775,17 +787,17 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     const size_t shmem = (size_t)tile_size * tile_size * 40;
     if (D == 4)
         hipLaunchKernelGGL(raster_fwd_ref_kernel<4>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
-                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           opacities, backgrounds, tile_masks, NS, D, width, height, tile_size, tile_width,
                            tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
                            render_alphas, last_ids);
     else if (D == 3)
         hipLaunchKernelGGL(raster_fwd_ref_kernel<3>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
-                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           opacities, backgrounds, tile_masks, NS, D, width, height, tile_size, tile_width,
                            tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
                            render_alphas, last_ids);
     else
         hipLaunchKernelGGL(raster_fwd_ref_kernel<0>, grid, block, shmem, sc_s(stream), means2d, conics, colors,
-                           opacities, backgrounds, tile_masks, N, D, width, height, tile_size, tile_width,
+                           opacities, backgrounds, tile_masks, NS, D, width, height, tile_size, tile_width,
                            tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
                            render_alphas, last_ids);
     SC_LAUNCH_CHECK();

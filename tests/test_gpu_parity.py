@@ -178,6 +178,23 @@ def test_isect_depth_ties_keep_index_order(ops, mode, n_depths):
     np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, tw, th))
 
 
+def test_isect_bin_falls_back_when_a_super_tile_overflows_lds(ops):
+    """> 7168 records in one 2x2 super-tile: the bucketed path reports SC_EUNSUPPORTED and the
+    wrapper must take the count/emit/radix route -- same bit-exact result."""
+    rng = np.random.default_rng(5)
+    N = 20000
+    m2 = rng.uniform(0, 32, size=(1, N, 2)).astype(np.float32)          # everything inside one super-tile
+    r = rng.integers(1, 6, size=(1, N)).astype(np.int32)
+    d = rng.uniform(1.0, 50.0, size=(1, N)).astype(np.float32)
+    e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 6, 4)
+    tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 6, 4)
+    off = ops.isect_offset_encode(ids, 1, 6, 4)
+    np.testing.assert_array_equal(_np(tpg), e_tpg)
+    np.testing.assert_array_equal(_np(ids), e_ids)
+    np.testing.assert_array_equal(_np(fids), e_f)
+    np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, 6, 4))
+
+
 def test_radix_sort_large_stable(ops):
     """4.2 M pairs with heavy key duplication vs torch.sort(stable=True) (same device)."""
     from street_crafter_amd import _lib
