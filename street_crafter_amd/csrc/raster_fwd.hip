@@ -14,7 +14,7 @@
 // to ~1e-6 relative, not bitwise (tolerance stated in tests/test_gpu_parity.py).
 #include "raster_common.h"
 
-int g_sc_raster_fwd_variant = 4;
+int g_sc_raster_fwd_variant = 3;
 
 namespace {
 
