@@ -145,7 +145,8 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      int C, int N, int D, int width, int height, int tile_size,
                      int tile_width, int tile_height,
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
-                     float* render_colors, float* render_alphas, int32_t* last_ids,
+                     float* render_colors, float* render_alphas,
+                     int32_t* last_ids /* nullable: only the backward pass reads it */,
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,N,D) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
 /* scratch for the packed-record fast path (64 B per (camera, splat)); without it the kernels gather

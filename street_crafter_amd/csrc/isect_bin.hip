@@ -149,77 +149,88 @@ __device__ __forceinline__ long long block_scan_1024(long long sum, unsigned mx,
     return run;
 }
 
-// single workgroup: 2-D prefix sum of a difference grid [C][gh+1][gw+1] -> per-cell counts ->
-// exclusive scan in (camera, row, column) order -> out[C*gh*gw]; meta[0] = total, meta[1] = max.
-__global__ __launch_bounds__(1024) void grid_scan_kernel(const int* __restrict__ dgrid, int C, int gw, int gh,
-                                                         int32_t* __restrict__ out, int64_t* __restrict__ meta) {
+// In-LDS inclusive prefix along one strided line of n cells; 8 consecutive lanes share a line
+// (each scans a segment serially, segment totals are combined with width-8 shuffles).  Every lane
+// of the wave must call it; lanes with active == false touch no memory.
+__device__ __forceinline__ void line_prefix8(int* base, int n, int stride, int sub, bool active) {
+    const int seg = (n + 7) >> 3;
+    const int b = sub * seg, e = min(n, b + seg);
+    int run = 0;
+    if (active)
+        for (int i = b; i < e; ++i) { run += base[i * stride]; base[i * stride] = run; }
+    int incl = run;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const int tmp = __shfl_up(incl, d, 8);
+        if (sub >= d) incl += tmp;
+    }
+    const int off = incl - run;
+    if (active && off)
+        for (int i = b; i < e; ++i) base[i * stride] += off;
+}
+
+// One launch, three independent single-workgroup jobs (blockIdx.x):
+//   0: tile difference grid  -> per-tile counts -> exclusive scan = isect_offsets; meta[0..1]
+//   1: super-tile difference grid -> record offsets;                               meta[2..3]
+//   2: centre histogram -> start of each centre bucket in the spatial order;       cmeta[0..1]
+// A difference grid [C][gh+1][gw+1] becomes counts by a 2-D prefix sum (x then y).
+struct ScanJob { const int* src; int C, gw, gh; int32_t* out; int64_t* meta; int is_grid; };
+struct ScanJobs { ScanJob j[3]; };
+
+__global__ __launch_bounds__(1024) void bin_scan_kernel(ScanJobs jobs) {
     extern __shared__ int grid[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
+    const ScanJob job = jobs.j[blockIdx.x];
     const int t = threadIdx.x;
-    const int W = gw + 1, H = gh + 1, ncell = C * H * W;
-    for (int i = t; i < ncell; i += 1024) grid[i] = dgrid[i];
-    __syncthreads();
-    const int lane = sc_lane(), wave = t >> 6;
-    for (int r = wave; r < C * H; r += 16) {         // prefix along x: one wave per row, 64 cells a step
-        int* row = grid + r * W;
-        int carry = 0;
-        for (int x0 = 0; x0 < W; x0 += 64) {
-            const int x = x0 + lane;
-            const int v = x < W ? row[x] : 0;
-            const int incl = sc_wave_incl_scan(v) + carry;
-            if (x < W) row[x] = incl;
-            carry = __shfl(incl, 63, 64);
-        }
-    }
-    __syncthreads();
-    for (int c = wave; c < C * W; c += 16) {         // prefix along y: one wave per column
-        const int cam = c / W, x = c - cam * W;
-        int* col = grid + cam * H * W + x;
-        int carry = 0;
-        for (int y0 = 0; y0 < H; y0 += 64) {
-            const int y = y0 + lane;
-            const int v = y < H ? col[y * W] : 0;
-            const int incl = sc_wave_incl_scan(v) + carry;
-            if (y < H) col[y * W] = incl;
-            carry = __shfl(incl, 63, 64);
-        }
-    }
-    __syncthreads();
+    const int gw = job.gw, gh = job.gh, C = job.C;
     const int n = C * gh * gw;
     const int per = (n + 1023) / 1024;
-    const int beg = t * per, end = min(beg + per, n);
-    auto cell = [&](int i) -> unsigned {
-        const int cam = i / (gh * gw), rem = i - cam * gh * gw;
-        const int y = rem / gw, x = rem - y * gw;
-        return (unsigned)grid[(cam * H + y) * W + x];
-    };
+    const int beg = min(t * per, n), end = min(beg + per, n);
     long long sum = 0;
     unsigned mx = 0;
-    for (int i = beg; i < end; ++i) { const unsigned c = cell(i); sum += c; mx = max(mx, c); }
     long long tot;
     unsigned m;
-    long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
-    for (int i = beg; i < end; ++i) { out[i] = (int32_t)run; run += cell(i); }
-    if (t == 0) { meta[0] = tot; meta[1] = (long long)m; }
-}
-
-// single workgroup: out = exclusive scan of counts; meta[0] = total, meta[1] = max count
-__global__ __launch_bounds__(1024) void hist_scan_kernel(const unsigned* __restrict__ counts, int n,
-                                                         int32_t* __restrict__ out, int64_t* __restrict__ meta) {
-    __shared__ long long wave_tot[16];
-    __shared__ unsigned wave_max[16];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int beg = t * per, end = min(beg + per, n);
-    long long sum = 0;
-    unsigned mx = 0;
-    for (int i = beg; i < end; ++i) { const unsigned c = counts[i]; sum += c; mx = max(mx, c); }
-    long long tot;
-    unsigned m;
-    long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
-    for (int i = beg; i < end; ++i) { out[i] = (int32_t)run; run += counts[i]; }
-    if (t == 0) { meta[0] = tot; meta[1] = (long long)m; }
+    if (job.is_grid) {
+        const int W = gw + 1, H = gh + 1, ncell = C * H * W;
+        for (int i = t; i < ncell; i += 1024) grid[i] = job.src[i];
+        __syncthreads();
+        const int sub = t & 7;
+        for (int l0 = 0; l0 < C * H; l0 += 128) {           // prefix along x (rows)
+            const int l = l0 + (t >> 3);
+            line_prefix8(grid + min(l, C * H - 1) * W, W, 1, sub, l < C * H);
+        }
+        __syncthreads();
+        for (int l0 = 0; l0 < C * W; l0 += 128) {           // prefix along y (columns)
+            const int l = min(l0 + (t >> 3), C * W - 1);
+            const int cam = l / W, x = l - cam * W;
+            line_prefix8(grid + cam * H * W + x, H, W, sub, l0 + (t >> 3) < C * W);
+        }
+        __syncthreads();
+        // exclusive scan over (camera, row, column); the cell index walks incrementally
+        int cam = beg / (gh * gw), rem = beg - cam * gh * gw;
+        int y = rem / gw, x = rem - y * gw;
+        const int cam0 = cam, y0 = y, x0 = x;
+        for (int i = beg; i < end; ++i) {
+            const unsigned c = (unsigned)grid[(cam * H + y) * W + x];
+            sum += c;
+            mx = max(mx, c);
+            if (++x == gw) { x = 0; if (++y == gh) { y = 0; ++cam; } }
+        }
+        long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
+        cam = cam0; y = y0; x = x0;
+        for (int i = beg; i < end; ++i) {
+            job.out[i] = (int32_t)run;
+            run += (unsigned)grid[(cam * H + y) * W + x];
+            if (++x == gw) { x = 0; if (++y == gh) { y = 0; ++cam; } }
+        }
+    } else {
+        const unsigned* counts = reinterpret_cast<const unsigned*>(job.src);
+        for (int i = beg; i < end; ++i) { const unsigned c = counts[i]; sum += c; mx = max(mx, c); }
+        long long run = block_scan_1024(sum, mx, &tot, &m, wave_tot, wave_max);
+        for (int i = beg; i < end; ++i) { job.out[i] = (int32_t)run; run += counts[i]; }
+    }
+    if (t == 0) { job.meta[0] = tot; job.meta[1] = (long long)m; }
 }
 
 // ---- spatial order: counting sort of the visible Gaussians by centre super-tile --------------------
@@ -739,22 +750,20 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)grid_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        SC_HIP(hipFuncSetAttribute((const void*)bin_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     hipLaunchKernelGGL(bin_count_kernel, dim3(grid), dim3(BIN_THREADS), count_lds_bytes(L), s, means2d, radii, CN,
                        L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
     SC_LAUNCH_CHECK();
-    // tiles: offsets + meta[0] (total intersections), meta[1] (largest tile)
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), (size_t)L.nt_cells * 4, s, (const int*)dgrid_t, C,
-                       tile_width, tile_height, isect_offsets, meta_dev);
-    SC_LAUNCH_CHECK();
-    // super-tiles: record offsets + meta[2] (total records), meta[3] (largest super-tile)
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), (size_t)L.ns_cells * 4, s, (const int*)dgrid_s, C,
-                       L.g.stw, L.g.sth, soffsets, meta_dev + 2);
-    SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned*)chist, L.nsb, cstart, cmeta);
+    // one launch: tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3];
+    // centre histogram -> spatial-order bucket starts
+    ScanJobs jobs;
+    jobs.j[0] = ScanJob{(const int*)dgrid_t, C, tile_width, tile_height, isect_offsets, meta_dev, 1};
+    jobs.j[1] = ScanJob{(const int*)dgrid_s, C, L.g.stw, L.g.sth, soffsets, meta_dev + 2, 1};
+    jobs.j[2] = ScanJob{(const int*)chist, 1, L.nsb, 1, cstart, cmeta, 0};
+    hipLaunchKernelGGL(bin_scan_kernel, dim3(3), dim3(1024), (size_t)L.nt_cells * 4, s, jobs);
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)L.nsb * 8, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,

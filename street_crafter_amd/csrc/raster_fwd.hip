@@ -54,7 +54,7 @@ __global__ void raster_fwd_ref_kernel(
             for (int d = 0; d < D; ++d)
                 render_colors[pix * D + d] = backgrounds ? backgrounds[cam * D + d] : 0.f;
             render_alphas[pix] = 0.f;
-            last_ids[pix] = 0;
+            if (last_ids) last_ids[pix] = 0;
         }
         return;
     }
@@ -118,7 +118,7 @@ __global__ void raster_fwd_ref_kernel(
         for (int d = 0; d < ND; ++d)
             if (CDIM > 0 || d < D)
                 render_colors[pix * D + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * D + d] : pix_out[d];
-        last_ids[pix] = cur_idx;
+        if (last_ids) last_ids[pix] = cur_idx;
     }
 }
 
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
             for (int d = 0; d < CDIM; ++d)
                 render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
             render_alphas[pix] = 0.f;
-            last_ids[pix] = 0;
+            if (last_ids) last_ids[pix] = 0;
         }
         return;
     }
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
             for (int d = 0; d < CDIM; ++d)
                 render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
         }
-        last_ids[pix] = cur_idx;
+        if (last_ids) last_ids[pix] = cur_idx;
     }
 }
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
             for (int d = 0; d < CDIM; ++d)
                 render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
             render_alphas[pix] = 0.f;
-            last_ids[pix] = 0;
+            if (last_ids) last_ids[pix] = 0;
         }
         return;
     }
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
             for (int d = 0; d < CDIM; ++d)
                 render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
         }
-        last_ids[pix] = cur_idx;
+        if (last_ids) last_ids[pix] = cur_idx;
     }
 }
 
@@ -486,7 +486,9 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
 // ------------------------------------------------------------------------------------------
 // PACKED: the splat parameters come from 64-byte records written by raster_pack_kernel (one
 // 64-B transaction per staged splat instead of four or five 4..16-B gathers from four arrays).
-template <int CDIM, bool PACKED>
+// TRACK: record last_ids (the sorted index of the last splat each pixel blended), needed only by
+// the backward pass; inference launches the variant without it.
+template <int CDIM, bool PACKED, bool TRACK>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
                 for (int d = 0; d < CDIM; ++d)
                     render_colors[(pix0 + k) * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
                 render_alphas[pix0 + k] = 0.f;
-                last_ids[pix0 + k] = 0;
+                if (last_ids) last_ids[pix0 + k] = 0;
             }
         }
         return;
@@ -645,14 +647,15 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
                     const bool term = valid && (next_T <= SC_T_EPS);
                     done[k] = done[k] || term;
                     const bool blend = valid && !term;
-                    const float vis = blend ? __fmul_rn(alpha, T[k]) : 0.f;
+                    const float a_eff = blend ? alpha : 0.f;      // one select drives vis AND the T update
+                    const float vis = __fmul_rn(a_eff, T[k]);
                     // adding c*0 leaves the sums bit-identical to skipping (sums are never -0)
                     acc[k][0] = __fmaf_rn(c.x, vis, acc[k][0]);
                     acc[k][1] = __fmaf_rn(c.y, vis, acc[k][1]);
                     acc[k][2] = __fmaf_rn(c.z, vis, acc[k][2]);
                     if (CDIM > 3) acc[k][3] = __fmaf_rn(c.w, vis, acc[k][3]);
-                    cur[k] = blend ? sidx : cur[k];
-                    T[k] = blend ? next_T : T[k];
+                    if (TRACK) cur[k] = blend ? sidx : cur[k];
+                    T[k] = sc_next_T(T[k], a_eff);                // == next_T when blending, == T[k] otherwise
                 }
                 if (__all(done[0] && done[1] && done[2] && done[3])) break;
                 a = an; bc = bcn; c = cn;
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             for (int d = 0; d < CDIM; ++d)
                 render_colors[pix * CDIM + d] = backgrounds ? acc[k][d] + T[k] * backgrounds[cam * CDIM + d] : acc[k][d];
         }
-        last_ids[pix] = cur[k];
+        if (TRACK) last_ids[pix] = cur[k];
     }
 }
 
@@ -716,7 +719,7 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
     if ((int64_t)tile_width * tile_size < width || (int64_t)tile_height * tile_size < height) return SC_EINVAL;
     if (C == 0) return SC_OK;
-    if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return SC_EINVAL;
+    if (!isect_offsets || !render_colors || !render_alphas) return SC_EINVAL;   // last_ids is nullable
     if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return SC_EINVAL;
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     dim3 grid(tile_width, tile_height, C);
@@ -730,8 +733,8 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
         const bool packed = variant == 4 && workspace && ws_bytes >= sc_rasterize_workspace_bytes(C, N, D) &&
                             n_isects > 0;
         float4* recs = packed ? (float4*)workspace : nullptr;
-#define SC_LAUNCH_WAVE(CD, PK)                                                                                  \
-    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
+#define SC_LAUNCH_WAVE(CD, PK, TR)                                                                                  \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
                        conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, NS, width, height,  \
                        tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,            \
                        render_colors, render_alphas, last_ids, g_sc_debug[1])
@@ -740,15 +743,15 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
             if (D == 4) {
                 hipLaunchKernelGGL(raster_pack_kernel<4>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
                                    colors, opacities, CN, recs);
-                SC_LAUNCH_WAVE(4, true);
+                if (last_ids) SC_LAUNCH_WAVE(4, true, true); else SC_LAUNCH_WAVE(4, true, false);
             } else {
                 hipLaunchKernelGGL(raster_pack_kernel<3>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
                                    colors, opacities, CN, recs);
-                SC_LAUNCH_WAVE(3, true);
+                if (last_ids) SC_LAUNCH_WAVE(3, true, true); else SC_LAUNCH_WAVE(3, true, false);
             }
         } else {
-            if (D == 4) SC_LAUNCH_WAVE(4, false);
-            else SC_LAUNCH_WAVE(3, false);
+            if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, false, true); else SC_LAUNCH_WAVE(4, false, false); }
+            else { if (last_ids) SC_LAUNCH_WAVE(3, false, true); else SC_LAUNCH_WAVE(3, false, false); }
         }
 #undef SC_LAUNCH_WAVE
         SC_LAUNCH_CHECK();

@@ -328,7 +328,12 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
         assert masks.shape == dirs.shape[:-1], masks.shape
         if not masks.is_cuda:
             raise RuntimeError("masks must live on a HIP device")
-        masks = masks.to(torch.uint8).contiguous() if masks.dtype != torch.uint8 else masks.contiguous()
+        if masks.dtype == torch.bool:
+            masks = masks.contiguous().view(torch.uint8)      # same bytes (0/1), no conversion kernel
+        elif masks.dtype != torch.uint8:
+            masks = masks.to(torch.uint8).contiguous()
+        else:
+            masks = masks.contiguous()
     return _SphericalHarmonics.apply(int(degrees_to_use), dirs, coeffs, masks)
 
 
@@ -346,7 +351,9 @@ class _Rasterize(torch.autograd.Function):
         dev = means2d.device
         render_colors = torch.empty((C, height, width, D), dtype=torch.float32, device=dev)
         render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
-        last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev)
+        # last_ids only feeds the backward replay: inference (no input requires grad) skips it
+        needs_bwd = any(ctx.needs_input_grad[:5])
+        last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev) if needs_bwd else None
         ws = _ws(lib.sc_rasterize_workspace_bytes(C, N, D), dev)
         _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
                                         _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
@@ -357,7 +364,7 @@ class _Rasterize(torch.autograd.Function):
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,
                               masks if masks is not None else e, isect_offsets, flatten_ids, render_alphas,
-                              last_ids)
+                              last_ids if last_ids is not None else e)
         ctx.meta = (int(width), int(height), int(tile_size), bool(absgrad), backgrounds is not None,
                     masks is not None)
         ctx.means2d_obj = means2d_obj

@@ -1,0 +1,54 @@
+"""fwd+bwd step timing of the caller's sequence (BASELINE config 3 shape: train-mode render +
+loss.backward()) on a synthetic scene.  Prints ms per step and the backward share.
+
+    python tools/exp_train.py [n_gauss] [width] [height] [steps]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 1600     # the reference trains at 1600x1066 (camera_utils.py:150-152)
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1066
+STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+dev = "cuda"
+scene = make_scene(N).to(dev)
+cam = make_camera(W, H, 2050.0 * W / 1920.0, 2050.0 * W / 1920.0).to(dev)
+for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh):
+    t.requires_grad_(True)
+target = torch.rand(3, H, W, device=dev)
+
+
+def step():
+    for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh):
+        t.grad = None
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    out = render_gaussians(scene, cam, mode="train")
+    loss = (out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()
+    e1.record()
+    loss.backward()
+    e2.record()
+    return e0, e1, e2, out
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+evs = [step() for _ in range(STEPS)]
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / STEPS
+fwd = sorted(a.elapsed_time(b) for a, b, _, _ in evs)[STEPS // 2]
+bwd = sorted(b.elapsed_time(c) for _, b, c, _ in evs)[STEPS // 2]
+vp = evs[-1][3]["viewspace_points"]
+print(f"N={N} {W}x{H}: wall {wall * 1e3:.3f} ms/step  fwd {fwd:.3f} ms  bwd {bwd:.3f} ms  "
+      f"it/s {1.0 / wall:.1f}  absgrad set: {hasattr(vp, 'absgrad')}", flush=True)
