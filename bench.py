@@ -72,15 +72,25 @@ def cpu_baseline(width, height, hip_frame_fn):
     t0 = time.perf_counter()
     exp = O.render_frame(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(),
                          sc.sh.numpy(), cam.viewmat.numpy(), cam.K.numpy(), width, height, sc.sh_degree,
-                         near_plane=cam.znear, far_plane=cam.zfar)
+                         near_plane=cam.znear, far_plane=cam.zfar, return_unstable=True)
     dt = time.perf_counter() - t0
     got = hip_frame_fn(sc, cam)
     ref_rgb = np.clip(exp["render_colors"][0, ..., :3], 0.0, 1.0)
-    psnr = O.psnr(got["rgb"], ref_rgb)
-    max_abs = float(np.abs(got["rgb"] - ref_rgb).max())
-    ints_ok = bool(np.array_equal(got["isect_ids"], exp["isect_ids"]) and
-                   np.array_equal(got["flatten_ids"], exp["flatten_ids"]))
-    return dt, int(exp["isect_ids"].shape[0]), psnr, max_abs, ints_ok
+    err = np.abs(got["rgb"] - ref_rgb).max(axis=-1)
+    # pixels where some alpha / transmittance sits within 2e-5 (relative) of a hard threshold can
+    # legitimately flip on a 1-ulp exp difference (oracle flags them); reported separately
+    stable = ~exp["unstable"][0]
+    parity = {
+        "psnr_db_vs_oracle": O.psnr(got["rgb"], ref_rgb),
+        "max_abs_rgb_stable_pixels": float(err[stable].max()),
+        "max_abs_rgb_all_pixels": float(err.max()),
+        "threshold_unstable_pixels": int((~stable).sum()),
+        "pixels_over_1e-4": int((err > 1e-4).sum()),
+        "n_pixels": int(err.size),
+        "isect_ids_and_flatten_ids_bit_exact": bool(np.array_equal(got["isect_ids"], exp["isect_ids"]) and
+                                                    np.array_equal(got["flatten_ids"], exp["flatten_ids"])),
+    }
+    return dt, int(exp["isect_ids"].shape[0]), parity
 
 
 def main():
@@ -185,7 +195,7 @@ def main():
                                    f"GPU per step, uint8 frames gathered to rank 0",
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
                        "isect_mode": rendering._ISECT_MODE["mode"], "parallelism": f"frames x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dom_gbs, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": dominant + " (operator; its kernels: DESIGN.md section 4)", "achieved": dom_gbs, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": dom_gbs / (HBM_PEAK / 1e9), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dominant]},
             "frame_roofline": {"algorithmic_bytes_per_frame": b_alg,
@@ -204,7 +214,7 @@ def main():
                 return {"rgb": o["rgb"].permute(1, 2, 0).cpu().numpy(), "isect_ids": o["_isect_ids"].cpu().numpy(),
                         "flatten_ids": o["_flatten_ids"].cpu().numpy()}
 
-            dt, I100k, psnr, max_abs, ints_ok = cpu_baseline(W, H, hip_frame)
+            dt, I100k, parity = cpu_baseline(W, H, hip_frame)
             scale = I100k / max(I_mean, 1.0)
             line["cpu_baseline"] = {
                 "value": (1.0 / dt) * scale, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -212,8 +222,7 @@ def main():
                           f"(I={I100k}) took {dt:.2f} s; value = 1/that, scaled by I_100k/I_1M={scale:.4f} "
                           f"to the S-1M unit (work ~ intersections)",
                 "measured_fps_at_100k": 1.0 / dt, "host_cpus": os.cpu_count()}
-            line["parity_100k"] = {"psnr_db_vs_oracle": psnr, "max_abs_rgb": max_abs,
-                                   "isect_ids_and_flatten_ids_bit_exact": ints_ok}
+            line["parity_100k"] = parity
         if args.stage_times:
             print(json.dumps(stage_ms, indent=1), file=sys.stderr)
         print(json.dumps(line), flush=True)
