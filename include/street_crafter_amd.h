@@ -181,6 +181,7 @@ int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,
  *                     2 = culled + software-pipelined gathers + XCD-aware tile map,
  *                     3 = one wave per tile, 4 pixels per lane, 4 = 3 + packed 64-B records (default)
+ *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)
  * Returns the previous value, or SC_EINVAL for an unknown key. */

@@ -28,6 +28,12 @@ extern "C" int sc_set_option(const char* key, int value) {
         g_sc_debug[key[5] - '0'] = value;
         return prev;
     }
+    if (strcmp(key, "raster_bwd") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_raster_bwd_variant;
+        g_sc_raster_bwd_variant = value;
+        return prev;
+    }
     if (strcmp(key, "raster_fwd") == 0) {
         if (value < 0 || value > 4) return SC_EINVAL;
         const int prev = g_sc_raster_fwd_variant;

@@ -52,4 +52,44 @@ __device__ __forceinline__ int sc_safe_id(int g, int n_splats) {
     return ((unsigned)g < (unsigned)n_splats) ? g : -1;
 }
 
+// ---- exact tile-level cull, shared by forward and backward ------------------------------------
+// Minimum of q(x,y) = 0.5*(A x^2 + C y^2) + B x y  over the rectangle [x0,x1] x [y0,y1]
+// (coordinates relative to the splat centre).  q is a convex quadratic when the conic is
+// positive definite; returns 0 if the centre is inside.
+__device__ __forceinline__ float min_quad_on_rect(float A, float Bc, float Cc, float x0, float x1,
+                                                  float y0, float y1) {
+    if (x0 <= 0.f && x1 >= 0.f && y0 <= 0.f && y1 >= 0.f) return 0.f;
+    float best = 3.0e38f;
+    // vertical edges x = xe: minimise over y -> y* = -B xe / C clamped
+    const float invC = 1.0f / Cc, invA = 1.0f / A;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float xe = e ? x1 : x0;
+        float ys = fminf(fmaxf(-Bc * xe * invC, y0), y1);
+        best = fminf(best, 0.5f * (A * xe * xe + Cc * ys * ys) + Bc * xe * ys);
+        const float ye = e ? y1 : y0;
+        float xs = fminf(fmaxf(-Bc * ye * invA, x0), x1);
+        best = fminf(best, 0.5f * (A * xs * xs + Cc * ye * ye) + Bc * xs * ye);
+    }
+    return best;
+}
+
+// True only when NO pixel centre inside the rectangle can pass the blend loop's test
+// (sigma >= 0 and op*exp(-sigma) >= 1/255, i.e. sigma <= ln(255 op)).  Conservative: the
+// threshold is widened by an absolute margin plus a bound on the fp32 rounding error of both
+// evaluations of the quadratic (2e-6 * the largest magnitude its terms reach on the rectangle);
+// NaN inputs and non positive-definite conics are never dropped (every comparison is false).
+__device__ __forceinline__ bool splat_misses_rect(float A, float Bc, float Cc, float op, float x0,
+                                                  float x1, float y0, float y1) {
+    const float L = __logf(255.0f * op);
+    if (L + 1e-3f + 1e-3f * fabsf(L) < 0.f) return true;   // op*255 < 1: alpha < 1/255 everywhere
+    const bool pd = (A > 0.f) && (Cc > 0.f) && (A * Cc - Bc * Bc > 0.f);
+    if (!pd) return false;
+    const float mx = fmaxf(fabsf(x0), fabsf(x1)), my = fmaxf(fabsf(y0), fabsf(y1));
+    const float S = A * mx * mx + Cc * my * my + 2.0f * fabsf(Bc) * mx * my;
+    const float tau = L + 1e-3f + 1e-3f * fabsf(L) + 2e-6f * S;
+    return min_quad_on_rect(A, Bc, Cc, x0, x1, y0, y1) > tau;
+}
+
+extern int g_sc_raster_bwd_variant;  // sc_set_option "raster_bwd"
 extern int g_sc_raster_fwd_variant;  // see include/street_crafter_amd.h (sc_set_option "raster_fwd")

@@ -390,8 +390,12 @@ def test_sh_backward_vs_autograd(ops, deg):
     assert float(ch.grad[..., K:, :].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("bwd_variant", [0, 1])
 @pytest.mark.parametrize("D,use_bg", [(4, False), (3, True), (6, False)])
-def test_rasterize_backward_vs_autograd(ops, golden_dir, D, use_bg):
+def test_rasterize_backward_vs_autograd(ops, golden_dir, D, use_bg, bwd_variant):
+    """bwd_variant 0 = reference-shaped kernel, 1 = one wave per tile (DPP reductions); D = 6 always
+    takes the reference-shaped kernel."""
+    from street_crafter_amd import _lib
     g = _load(golden_dir, "pipeline_small.npz")
     rng = np.random.default_rng(17 + D)
     N = g["means2d"].shape[0]
@@ -412,7 +416,11 @@ def test_rasterize_backward_vs_autograd(ops, golden_dir, D, use_bg):
     rc, ra = ops.rasterize_to_pixels(hip[0], hip[1], hip[2], hip[3], W, H, 16, _t(g["isect_offsets"], torch.int32),
                                      _t(g["flatten_ids"], torch.int32), backgrounds=None if bg is None else _t(bg),
                                      absgrad=True)
-    ((rc * _t(w_c)).sum() + (ra * _t(w_a)).sum()).backward()
+    prev = _lib.set_option("raster_bwd", bwd_variant)
+    try:
+        ((rc * _t(w_c)).sum() + (ra * _t(w_a)).sum()).backward()
+    finally:
+        _lib.set_option("raster_bwd", prev)
 
     ref = [torch.from_numpy(a).double().requires_grad_(True) for a in src]
     rcr, rar = OT.rasterize_to_pixels(ref[0], ref[1], ref[2], ref[3], W, H, 16, torch.from_numpy(g["isect_offsets"]),

@@ -40,6 +40,9 @@ def step():
     return e0, e1, e2, out
 
 
+from street_crafter_amd import _lib  # noqa: E402
+if os.environ.get("SC_RASTER_BWD"):
+    _lib.set_option("raster_bwd", int(os.environ["SC_RASTER_BWD"]))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
