@@ -176,6 +176,9 @@ int sc_knn3_mean_dist2(const float* points, int64_t n, float* out, void* workspa
 int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8_t* out,
                    sc_stream_t stream);
 
+/* unit-test hook: out[w] = sum(in[64 w .. 64 w + 63]) with the backward kernel's DPP wave reduction */
+int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,

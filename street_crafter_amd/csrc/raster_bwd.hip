@@ -367,7 +367,22 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     }
 }
 
+// unit-test hook for the DPP reduction: out[w] = sum of in[64 w .. 64 w + 63]
+__global__ __launch_bounds__(64) void test_wave_reduce_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    const float v = wave_sum_to_lane63(in[blockIdx.x * 64 + threadIdx.x]);
+    if (threadIdx.x == 63) out[blockIdx.x] = v;
+}
+
 }  // namespace
+
+extern "C" int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream) {
+    if (n_waves < 0) return SC_EINVAL;
+    if (n_waves == 0) return SC_OK;
+    if (!in || !out) return SC_EINVAL;
+    hipLaunchKernelGGL(test_wave_reduce_kernel, dim3(n_waves), dim3(64), 0, sc_s(stream), in, out);
+    SC_LAUNCH_CHECK();
+    return SC_OK;
+}
 
 extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
                                 const float* opacities, const float* backgrounds,
