@@ -267,31 +267,36 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
 
     for (int hi = tile_last; hi >= range_start; hi -= B) {
         // ---- stage (descending sorted index), cull, compact ----------------------------------------
+        // Same shape as raster_fwd_wave_kernel's staging: parameters land in plain scalars, the cull
+        // result is one bool, and the record is built at the LDS store.  (Carrying whole float4
+        // records through the `if (keep)` merge was miscompiled by hipcc 7.2 for gfx950: the j = 1
+        // record lost its mean; tests/test_gpu_parity.py::test_rasterize_backward_wave_matches_reference
+        // guards against a recurrence.)
         int bsz = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             const int idx = hi - (j * 64 + lane);
-            bool keep = false;
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0;
             const int g = (idx >= range_start) ? sc_safe_id(flatten_ids[idx], N) : -1;
+            float2 xy = make_float2(0.f, 0.f);
+            float ca = 0.f, cb = 0.f, cc = 0.f, op = 0.f;
+            bool keep = false;
             if (g >= 0) {
-                const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+                xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
                 const float* cn = conics + (int64_t)g * 3;
-                const float ca = cn[0], cb = cn[1], cc = cn[2], op = opacities[g];
-                keep = !splat_misses_rect(ca, cb, cc, op, rx0 - xy.x, rx1 - xy.x, ry0 - xy.y, ry1 - xy.y);
-                if (keep) {
-                    const ScSplat sp = sc_prescale(xy.x, xy.y, ca, cb, cc, op);
-                    const float* c = colors + (int64_t)g * CDIM;
-                    v0 = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
-                    v1 = make_float4(sp.B2, sp.C2, __int_as_float(idx), __int_as_float(g));
-                    v2 = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-                }
+                ca = cn[0]; cb = cn[1]; cc = cn[2];
+                op = opacities[g];
+                const bool miss = splat_misses_rect(ca, cb, cc, op, rx0 - xy.x, rx1 - xy.x, ry0 - xy.y, ry1 - xy.y);
+                keep = !miss;
             }
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int slot = bsz + __popcll(m & sc_lanemask_lt());
-                xyoa_s[slot] = v0; bck_s[slot] = v1; col_s[slot] = v2;
+                const ScSplat sp = sc_prescale(xy.x, xy.y, ca, cb, cc, op);
+                const float* c = colors + (int64_t)g * CDIM;
+                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+                bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(idx), __int_as_float(g));
+                col_s[slot] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
             }
             bsz += __popcll(m);
         }
