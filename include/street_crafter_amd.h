@@ -178,6 +178,9 @@ int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8
 
 /* unit-test hook: out[w] = sum(in[64 w .. 64 w + 63]) with the backward kernel's DPP wave reduction */
 int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream);
+/* unit-test hook for the backward kernel's transposing reduction (v_permlane32/16_swap + DPP):
+ * in [n_waves][16][64] per-lane partial sums, out [n_waves][64]: lane l = 64-lane total of value l >> 2 */
+int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_stream_t stream);
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).

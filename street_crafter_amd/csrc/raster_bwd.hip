@@ -171,10 +171,14 @@ __global__ void raster_bwd_kernel(
 // ------------------------------------------------------------------------------------------
 // Wave-per-tile backward (tile 16x16, CDIM 3/4): the mirror image of raster_fwd_wave_kernel.
 //   * one wave per tile, 4 pixels per lane: each lane first sums the contributions of its own 4
-//     pixels, so the cross-lane reduction per splat is 12 values once per TILE (the reference-shaped
-//     kernel above reduces them once per 64 pixels, i.e. four times per tile);
-//   * the reduction is 6 DPP adds per value (row_shr 1/2/4/8, row_bcast 15/31: VALU ops, no LDS
-//     round trips), lane 63 then issues the float atomics;
+//     pixels, so the cross-lane reduction per splat happens once per TILE (the reference-shaped
+//     kernel above reduces once per 64 pixels, i.e. four times per tile);
+//   * the (up to) 12 per-splat sums are reduced TOGETHER by a transposing butterfly
+//     (wave_transpose_sum16): every stage halves the number of live registers while it halves the
+//     lanes that own a given sum - v_permlane32_swap / v_permlane16_swap (gfx950) for the two
+//     cross-row stages, DPP row_mirror / row_half_mirror / quad_perm for the rest.  ~35 VALU ops
+//     for all sums instead of 6 per sum, no LDS round trips, and lane 4 i ends up owning sum i, so
+//     ONE global_atomic_add_f32 with 12 active lanes replaces 12 single-lane atomics;
 //   * batches are staged back to front from the last splat any pixel of the tile blended, with the
 //     forward's exact tile-level cull + ballot compaction, so splats that touch no pixel of the tile
 //     (66 % of the walked ones on S-1M) cost one lane-test instead of 256 pixel evaluations;
@@ -194,6 +198,42 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
     v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// lanes 0..31 get a(l) + a(l + 32), lanes 32..63 get b(l - 32) + b(l)
+__device__ __forceinline__ float swap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// even rows get a(l) + a(l + 16), odd rows get b(l - 16) + b(l)   (row = 16 lanes)
+__device__ __forceinline__ float swap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// 16 per-lane partial sums in, one register out: lane l holds the 64-lane total of v[l >> 2].
+// Lane pairings per stage: l^32, l^16, l^15 (row_mirror), l^7 (row_half_mirror), l^2, l^1 - six
+// independent masks, so every lane's contribution reaches the owner of each sum exactly once.
+__device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16], int lane) {
+    float w[8], x[4], y[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = swap32_add(v[i], v[i + 8]);       // lane bit 5 picks +8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = swap16_add(w[i], w[i + 4]);       // lane bit 4 picks +4
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                         // lane bit 3 picks +2
+        const float keep = b3 ? x[i + 2] : x[i], give = b3 ? x[i] : x[i + 2];
+        y[i] = keep + dpp_move<0x140>(give);                              // row_mirror
+    }
+    const float keep = b2 ? y[1] : y[0], give = b2 ? y[0] : y[1];       // lane bit 2 picks +1
+    float z = keep + dpp_move<0x141>(give);                               // row_half_mirror
+    z += dpp_move<0x4E>(z);                                               // quad_perm [2,3,0,1]
+    z += dpp_move<0xB1>(z);                                               // quad_perm [1,0,3,2]
+    return z;
 }
 
 template <int CDIM>
@@ -265,6 +305,21 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
     constexpr float LN2 = 0.6931471805599453f;
 
+    // lane 4 i owns reduced sum i (wave_transpose_sum16): 0..3 colour channels, 4..6 conic, 7..8 mean,
+    // 9..10 |mean| (absgrad), 11 opacity.  out_base == nullptr: this lane issues no atomic.
+    float* out_base = nullptr;
+    int out_stride = 0;
+    {
+        const int vi = lane >> 2;
+        if ((lane & 3) == 0) {
+            if (vi < CDIM) { out_base = v_colors + vi; out_stride = CDIM; }
+            else if (vi >= 4 && vi <= 6) { out_base = v_conics + (vi - 4); out_stride = 3; }
+            else if (vi == 7 || vi == 8) { out_base = v_means2d + (vi - 7); out_stride = 2; }
+            else if ((vi == 9 || vi == 10) && v_means2d_abs) { out_base = v_means2d_abs + (vi - 9); out_stride = 2; }
+            else if (vi == 11) { out_base = v_opacities; out_stride = 1; }
+        }
+    }
+
     for (int hi = tile_last; hi >= range_start; hi -= B) {
         // ---- stage (descending sorted index), cull, compact ----------------------------------------
         // Same shape as raster_fwd_wave_kernel's staging: parameters land in plain scalars, the cull
@@ -308,10 +363,10 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
             const int sidx = __float_as_int(bc.z);
             const float dy = a.y - py;
             const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);
-            float s_rgb[CDIM];
+            const float inv_op = __builtin_amdgcn_exp2f(-a.z);              // 1 / opacity
+            float s[16];
 #pragma unroll
-            for (int d = 0; d < CDIM; ++d) s_rgb[d] = 0.f;
-            float s_c0 = 0.f, s_c1 = 0.f, s_c2 = 0.f, s_x = 0.f, s_y = 0.f, s_xa = 0.f, s_ya = 0.f, s_op = 0.f;
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
             bool any_valid = false;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -322,52 +377,35 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
                 const float alpha = fminf(SC_ALPHA_MAX, alpha_raw);          // == sc_alpha2(a.z, sigma2)
                 const bool valid = inside[k] && (sidx <= bin_final[k]) && sc_valid(sigma2, alpha);
                 any_valid = any_valid || valid;
-                const float ra = __frcp_rn(1.0f - alpha);
+                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);        // 1 - alpha >= 1e-3
                 const float Tn = T[k] * ra;                                   // transmittance in front of this splat
                 const float fac = valid ? alpha * Tn : 0.f;
                 float v_alpha = 0.f;
 #pragma unroll
                 for (int d = 0; d < CDIM; ++d) {
-                    s_rgb[d] += fac * v_rc[k][d];
+                    s[d] += fac * v_rc[k][d];
                     v_alpha += (cl[d] * Tn - buf[k][d] * ra) * v_rc[k][d];
                     buf[k][d] += cl[d] * fac;
                 }
                 v_alpha += T_final[k] * ra * (v_ra[k] - bgdot[k]);
                 // sigma = sigma2 ln2;  d alpha / d sigma = -alpha_raw (only while alpha is not clamped)
-                const float v_sigma = (valid && alpha_raw <= SC_ALPHA_MAX) ? -alpha_raw * v_alpha : 0.f;
-                s_c0 += 0.5f * v_sigma * dx * dx;
-                s_c1 += v_sigma * dx * dy;
-                s_c2 += 0.5f * v_sigma * dy * dy;
+                const bool live = valid && alpha_raw <= SC_ALPHA_MAX;
+                const float v_sigma = live ? -alpha_raw * v_alpha : 0.f;
+                s[4] += 0.5f * v_sigma * dx * dx;
+                s[5] += v_sigma * dx * dy;
+                s[6] += 0.5f * v_sigma * dy * dy;
                 // d sigma / d mean = (a dx + b dy, b dx + c dy) = ln2 (2 A2 dx + B2 dy, B2 dx + 2 C2 dy)
                 const float gx = v_sigma * LN2 * (2.0f * a.w * dx + bc.x * dy);
                 const float gy = v_sigma * LN2 * (bc.x * dx + 2.0f * bc.y * dy);
-                s_x += gx; s_y += gy;
-                s_xa += fabsf(gx); s_ya += fabsf(gy);
-                // d alpha / d op = exp(-sigma) = exp2(-sigma2)
-                s_op += (valid && alpha_raw <= SC_ALPHA_MAX) ? __builtin_amdgcn_exp2f(-sigma2) * v_alpha : 0.f;
+                s[7] += gx; s[8] += gy;
+                s[9] += fabsf(gx); s[10] += fabsf(gy);
+                // d alpha / d op = exp(-sigma) = alpha_raw / op
+                s[11] += live ? alpha_raw * inv_op * v_alpha : 0.f;
                 T[k] = valid ? Tn : T[k];
             }
             if (!__any(any_valid)) continue;
-#pragma unroll
-            for (int d = 0; d < CDIM; ++d) s_rgb[d] = wave_sum_to_lane63(s_rgb[d]);
-            s_c0 = wave_sum_to_lane63(s_c0); s_c1 = wave_sum_to_lane63(s_c1); s_c2 = wave_sum_to_lane63(s_c2);
-            s_x = wave_sum_to_lane63(s_x); s_y = wave_sum_to_lane63(s_y); s_op = wave_sum_to_lane63(s_op);
-            if (v_means2d_abs) { s_xa = wave_sum_to_lane63(s_xa); s_ya = wave_sum_to_lane63(s_ya); }
-            if (lane == 63) {
-                const int64_t g = __float_as_int(bc.w);
-#pragma unroll
-                for (int d = 0; d < CDIM; ++d) atomicAdd(v_colors + g * CDIM + d, s_rgb[d]);
-                atomicAdd(v_conics + g * 3 + 0, s_c0);
-                atomicAdd(v_conics + g * 3 + 1, s_c1);
-                atomicAdd(v_conics + g * 3 + 2, s_c2);
-                atomicAdd(v_means2d + g * 2 + 0, s_x);
-                atomicAdd(v_means2d + g * 2 + 1, s_y);
-                if (v_means2d_abs) {
-                    atomicAdd(v_means2d_abs + g * 2 + 0, s_xa);
-                    atomicAdd(v_means2d_abs + g * 2 + 1, s_ya);
-                }
-                atomicAdd(v_opacities + g, s_op);
-            }
+            const float total = wave_transpose_sum16(s, lane);
+            if (out_base) atomicAdd(out_base + (int64_t)__float_as_int(bc.w) * out_stride, total);
         }
     }
 }
@@ -378,7 +416,24 @@ __global__ __launch_bounds__(64) void test_wave_reduce_kernel(const float* __res
     if (threadIdx.x == 63) out[blockIdx.x] = v;
 }
 
+// unit-test hook for wave_transpose_sum16: in [n_waves][16][64], out [n_waves][64]
+__global__ __launch_bounds__(64) void test_wave_transpose_kernel(const float* __restrict__ in, float* __restrict__ out) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = in[((int64_t)blockIdx.x * 16 + i) * 64 + threadIdx.x];
+    out[(int64_t)blockIdx.x * 64 + threadIdx.x] = wave_transpose_sum16(v, threadIdx.x);
+}
+
 }  // namespace
+
+extern "C" int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_stream_t stream) {
+    if (n_waves < 0) return SC_EINVAL;
+    if (n_waves == 0) return SC_OK;
+    if (!in || !out) return SC_EINVAL;
+    hipLaunchKernelGGL(test_wave_transpose_kernel, dim3(n_waves), dim3(64), 0, sc_s(stream), in, out);
+    SC_LAUNCH_CHECK();
+    return SC_OK;
+}
 
 extern "C" int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream) {
     if (n_waves < 0) return SC_EINVAL;

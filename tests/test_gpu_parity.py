@@ -349,6 +349,29 @@ def test_dpp_wave_reduction_matches_sum():
     torch.testing.assert_close(got, x.double().sum(dim=1).float(), rtol=1e-5, atol=1e-5)
 
 
+def test_transposing_wave_reduction_routes_every_lane_once():
+    """wave_transpose_sum16 (v_permlane32/16_swap + DPP mirrors): lane l must end with the 64-lane total
+    of value l >> 2.  One-hot inputs check the routing exactly (every (value, lane) cell reaches its
+    owners once and nobody else), random inputs check the sums."""
+    from street_crafter_amd import _lib
+    lib = _lib.load()
+    n_hot = 16 * 64
+    x = torch.zeros(n_hot + 64, 16, 64)
+    for v in range(16):
+        for l in range(64):
+            x[v * 64 + l, v, l] = 1.0 + v + 100.0 * l        # distinct, exactly representable
+    x[n_hot:] = torch.randn(64, 16, 64, generator=torch.Generator().manual_seed(1))
+    xd = x.to(DEV)
+    out = torch.empty(n_hot + 64, 64, device=DEV)
+    _lib.check(lib.sc_test_wave_transpose_sum16(xd.data_ptr(), n_hot + 64, out.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream),
+               "sc_test_wave_transpose_sum16")
+    got = out.cpu()
+    want = x.double().sum(dim=2).float()[:, torch.arange(64) // 4]      # [waves, 64]: value l >> 2
+    assert torch.equal(got[:n_hot], want[:n_hot])
+    torch.testing.assert_close(got[n_hot:], want[n_hot:], rtol=1e-5, atol=1e-5)
+
+
 
 def _rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
