@@ -118,8 +118,12 @@ def spherical_harmonics(degree, dirs, coeffs, masks=None):
 
 
 def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_height,
-                        tile_size, isect_offsets, flatten_ids, backgrounds=None):
-    """Shapes as gsplat: [C,N,*]; returns render_colors [C,H,W,D], render_alphas [C,H,W,1]."""
+                        tile_size, isect_offsets, flatten_ids, backgrounds=None, pixel_grads=None):
+    """Shapes as gsplat: [C,N,*]; returns render_colors [C,H,W,D], render_alphas [C,H,W,1].
+
+    `pixel_grads`: optional list; when given, every tile appends (flat ids, dx, dy) with dx/dy
+    [G,P] retaining their gradients, so that after backward `absgrad_from_pixel_grads` can form
+    gsplat's absgrad = sum over pixels of |d loss / d mean2d through that pixel|."""
     C, N = opacities.shape
     D = colors.shape[-1]
     H, W = int(image_height), int(image_width)
@@ -160,6 +164,10 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
                 G = g.shape[0]
                 dx = m2[g, 0][:, None] - px[None, :]
                 dy = m2[g, 1][:, None] - py[None, :]
+                if pixel_grads is not None:
+                    dx.retain_grad()
+                    dy.retain_grad()
+                    pixel_grads.append((g, dx, dy))
                 ca, cb, cc = cn[g, 0][:, None], cn[g, 1][:, None], cn[g, 2][:, None]
                 sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
                 alpha_raw = op[g][:, None] * torch.exp(-sigma)
@@ -197,3 +205,15 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
         rows_c.append(img_c)
         rows_a.append(img_a)
     return torch.stack(rows_c), torch.stack(rows_a)
+
+
+def absgrad_from_pixel_grads(pixel_grads, n_flat):
+    """[n_flat, 2] = sum over (tile, pixel) of |grad of dx|, |grad of dy| per flat Gaussian id
+    (d dx / d mean_x = 1, so the per-pixel gradient of the mean IS the gradient of dx)."""
+    out = torch.zeros(n_flat, 2, dtype=torch.float64)
+    for g, dx, dy in pixel_grads:
+        if dx.grad is None:
+            continue
+        out[:, 0].index_add_(0, g, dx.grad.abs().sum(dim=1).double())
+        out[:, 1].index_add_(0, g, dy.grad.abs().sum(dim=1).double())
+    return out

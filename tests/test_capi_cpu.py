@@ -104,3 +104,40 @@ def test_product_path_never_imports_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_densification_stats_mirror_cpu():
+    """Host logic of the densification-statistics consumer (street_gaussian_model.py:487-521) on CPU
+    tensors: per-model slicing, absgrad/grad columns, pixel scaling, visibility gating, NaN -> 0."""
+    import torch
+    from street_crafter_amd.densify_stats import DensificationStats
+    n, W, H = 10, 200, 100
+    st = DensificationStats({"background": (0, 6), "obj_001": (6, 10)}, device="cpu")
+    vp = torch.zeros(1, n, 2)
+    vp.grad = torch.arange(2 * n, dtype=torch.float32).reshape(1, n, 2) * 0.01
+    vp.absgrad = vp.grad * 3.0
+    vis = torch.tensor([True, False] * 5)
+    radii = torch.arange(n, dtype=torch.int32)
+    st.set_max_radii2D(radii / float(max(H, W)), vis)
+    st.add_densification_stats(vp, vis, W, H)
+    st.add_densification_stats(vp, vis, W, H)
+    scale = torch.tensor([0.5 * W, 0.5 * H])
+    want_grad = 2 * torch.norm(vp.grad[0] * scale, dim=-1)
+    want_abs = 2 * torch.norm(vp.absgrad[0] * scale, dim=-1)
+    acc = torch.cat([st.xyz_gradient_accum["background"], st.xyz_gradient_accum["obj_001"]])
+    den = torch.cat([st.denom["background"], st.denom["obj_001"]])[:, 0]
+    assert torch.allclose(acc[vis, 0], want_abs[vis]) and torch.allclose(acc[vis, 1], want_grad[vis])
+    assert float(acc[~vis].abs().sum()) == 0.0
+    assert torch.equal(den, vis.float() * 2)
+    mr = torch.cat([st.max_radii2D["background"], st.max_radii2D["obj_001"]])
+    assert torch.allclose(mr[vis], radii[vis].float() / 200.0) and float(mr[~vis].sum()) == 0.0
+    g = st.mean_grads("obj_001", use_abs=True)
+    assert g.shape == (4, 1) and not torch.isnan(g).any() and float(g[1]) == 0.0   # invisible row: 0/0 -> 0
+    clone, split = st.clone_split_masks("background", 0.0, torch.tensor([0.001, 1, 0.001, 1, 0.001, 1.0]), 10.0)
+    assert clone.tolist() == [True, False, True, False, True, False] and split.tolist() == [False, True] * 3
+    # no absgrad attribute -> plain grad path (street_gaussian_model.py:510-511)
+    vp2 = torch.zeros(1, n, 2)
+    vp2.grad = torch.ones(1, n, 2)
+    st.reset()
+    st.add_densification_stats(vp2, vis, W, H)
+    assert torch.allclose(st.xyz_gradient_accum["background"][0], torch.tensor([2 ** 0.5, 0.0]))
