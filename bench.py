@@ -165,6 +165,37 @@ def main():
     if rank == 0:
         assert len(frames) == args.steps * world, (len(frames), args.steps, world)
 
+    # SURVEY 8f-2 (secondary, N = 1 only): the same frames through gsplat's one-call `rasterization()`,
+    # whose forward is fused (projection + SH + glue in one kernel, depth normalisation in the raster
+    # epilogue).  `value` above stays the reference caller's own operator sequence.
+    fused_line = None
+    if world == 1:
+        from gsplat.rendering import rasterization
+        op1 = scene.opacities[:, 0].contiguous()
+
+        def fused_step(s):
+            cam = cams[s]
+            with torch.no_grad():
+                rc, _, _ = rasterization(scene.means, scene.quats, scene.scales, op1, scene.sh, cam.viewmat[None],
+                                         cam.K[None], W, H, near_plane=cam.znear, far_plane=cam.zfar,
+                                         sh_degree=scene.sh_degree, render_mode="RGB+ED",
+                                         rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
+                return to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1))
+
+        for s in range(args.warmup):
+            fused_step(s)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        fused_frames = [fused_step(s) for s in range(args.warmup, total_steps)]
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        same = all(torch.equal(a, b) for a, b in zip(frames, fused_frames))
+        fused_line = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
+                      "frames_identical_to_caller_sequence": bool(same),
+                      "what": "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
+                              "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 4)"}
+        del fused_frames
+
     # per-operator device time from the HIP events recorded inside the timed region
     stage_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
     I_mean = sum(n_isects) / max(len(n_isects), 1)
@@ -205,6 +236,8 @@ def main():
                                "valu_pair_bound": 256 * I_mean},
             "stage_ms": stage_ms,
         }
+        if fused_line is not None:
+            line["fused_rasterization"] = fused_line
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
 

@@ -169,6 +169,33 @@ size_t sc_knn_workspace_bytes(int64_t n);
 int sc_knn3_mean_dist2(const float* points, int64_t n, float* out, void* workspace,
                        size_t ws_bytes, sc_stream_t stream);
 
+/* ---- fused forward behind gsplat.rendering.rasterization() (imported at
+ *      street_gaussian/models/street_gaussian_renderer.py:204) -------------------------------------
+ * sc_camera_centers: out[c] = -R^T t of the rigid world-to-camera matrices viewmats [C,4,4]
+ *   (= Camera.camera_center, street_gaussian/utils/camera_utils.py:51; gsplat takes inverse(viewmat)).
+ * sc_projection_sh_fwd: renderer.py:219-266 in one pass per (camera, Gaussian): projection, opacity *
+ *   compensation (when antialiased), dirs = mean - camera centre, SH colour where radius > 0,
+ *   clamp_min(colour + 0.5, 0), depth appended as 4th channel.  opacities [N], sh_coeffs [N,K,3];
+ *   outputs radii [C,N], means2d [C,N,2], depths [C,N], conics [C,N,3], opacities_out [C,N],
+ *   colors4 [C,N,4].  Bit-identical to the separate operators + torch glue.
+ * sc_rasterize_fwd_ed: sc_rasterize_fwd (no last_ids) whose 4th output channel is divided by
+ *   max(alpha, 1e-10) (renderer.py:284; gsplat render_mode "RGB+ED").  D must be 4 and tile_size 16,
+ *   otherwise SC_EUNSUPPORTED. */
+int sc_camera_centers(const float* viewmats, int C, float* out, sc_stream_t stream);
+int sc_projection_sh_fwd(const float* means, const float* quats, const float* scales,
+                         const float* opacities, const float* sh_coeffs, const float* viewmats,
+                         const float* Ks, const float* camera_centers, int C, int N, int K,
+                         int sh_degree, int width, int height, float eps2d, float near_plane,
+                         float far_plane, float radius_clip, int antialiased, int32_t* radii,
+                         float* means2d, float* depths, float* conics, float* opacities_out,
+                         float* colors4, sc_stream_t stream);
+int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,
+                        const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
+                        int C, int N, int D, int width, int height, int tile_size, int tile_width,
+                        int tile_height, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                        int64_t n_isects, float* render_colors, float* render_alphas, void* workspace,
+                        size_t ws_bytes, sc_stream_t stream);
+
 /* ---- frame export for the multi-GPU gather (no reference counterpart: the reference's visualizer
  *      does .cpu().numpy() per frame, street_gaussian/visualizers/street_gaussian_visualizer.py:82-101)
  * rgb: f32 pixels with `channel_stride` floats per pixel (>= 3; e.g. 4 for the RGB+depth image);

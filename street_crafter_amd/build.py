@@ -21,7 +21,7 @@ LIB = os.path.join(LIBDIR, "libstreet_crafter_hip.so")
 ARCH = "gfx950"
 
 SOURCES = ["capi.hip", "projection.hip", "isect.hip", "isect_bin.hip", "radix_sort.hip", "sh.hip",
-           "raster_fwd.hip", "raster_bwd.hip", "knn.hip"]
+           "raster_fwd.hip", "raster_bwd.hip", "knn.hip", "fused_fwd.hip"]
 COMMON_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
                 "-fno-gpu-rdc"]
 

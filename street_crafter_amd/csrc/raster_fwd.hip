@@ -636,6 +636,9 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
                 o.x += T[k] * backgrounds[cam * 4 + 0]; o.y += T[k] * backgrounds[cam * 4 + 1];
                 o.z += T[k] * backgrounds[cam * 4 + 2]; o.w += T[k] * backgrounds[cam * 4 + 3];
             }
+            // "RGB+ED" epilogue (sc_rasterize_fwd_ed): expected depth = depth sum / max(alpha, 1e-10),
+            // the caller's renderer.py:284 / gsplat rasterization() post-step, as one IEEE divide
+            if (dbg & 0x100) o.w = o.w / fmaxf(1.0f - T[k], 1e-10f);
             *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
         } else {
 #pragma unroll
@@ -670,13 +673,14 @@ extern "C" size_t sc_rasterize_workspace_bytes(int C, int N, int D) {
     return sc_align_up((size_t)C * N * 64, 256);
 }
 
-extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
-                                const float* opacities, const float* backgrounds,
-                                const uint8_t* tile_masks, int C, int N, int D, int width, int height,
-                                int tile_size, int tile_width, int tile_height,
-                                const int32_t* isect_offsets, const int32_t* flatten_ids,
-                                int64_t n_isects, float* render_colors, float* render_alphas,
-                                int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream) {
+static int rasterize_fwd_impl(const float* means2d, const float* conics, const float* colors,
+                              const float* opacities, const float* backgrounds,
+                              const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                              int tile_size, int tile_width, int tile_height,
+                              const int32_t* isect_offsets, const int32_t* flatten_ids,
+                              int64_t n_isects, float* render_colors, float* render_alphas,
+                              int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream,
+                              int epilogue) {
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
@@ -689,6 +693,9 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     if ((int64_t)C * N > 0x7fffffffLL) return SC_EINVAL;
     const int NS = C * N;                 // kernels bound-check flatten ids against C*N
     const int variant = g_sc_raster_fwd_variant;
+    // the depth-normalising epilogue exists in the wave-per-tile kernel with 4 channels only
+    if (epilogue && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
+    const int kdbg = g_sc_debug[1] | (epilogue ? 0x100 : 0);
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         const int total_tiles = C * tile_width * tile_height;
         const int64_t CN = (int64_t)C * N;
@@ -700,7 +707,7 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
                        conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, NS, width, height,  \
                        tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,            \
-                       render_colors, render_alphas, last_ids, g_sc_debug[1])
+                       render_colors, render_alphas, last_ids, kdbg)
         if (packed) {
             const unsigned pg = (unsigned)((CN + 255) / 256);
             if (D == 4) {
@@ -768,4 +775,28 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
                            render_alphas, last_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;
+}
+
+extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const float* colors,
+                                const float* opacities, const float* backgrounds,
+                                const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                                int tile_size, int tile_width, int tile_height,
+                                const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                int64_t n_isects, float* render_colors, float* render_alphas,
+                                int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream) {
+    return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
+                              tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
+                              render_colors, render_alphas, last_ids, workspace, ws_bytes, stream, 0);
+}
+
+extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,
+                                   const float* opacities, const float* backgrounds,
+                                   const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                                   int tile_size, int tile_width, int tile_height,
+                                   const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                   int64_t n_isects, float* render_colors, float* render_alphas,
+                                   void* workspace, size_t ws_bytes, sc_stream_t stream) {
+    return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
+                              tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
+                              render_colors, render_alphas, nullptr, workspace, ws_bytes, stream, 1);
 }

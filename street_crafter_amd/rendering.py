@@ -456,6 +456,96 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
 # ------------------------------------------------------------------------------------------
 # a13 rasterization  (imported at renderer.py:204, never called there): thin composition
 # ------------------------------------------------------------------------------------------
+def camera_centers(viewmats: Tensor) -> Tensor:
+    """[C,3] camera positions -R^T t of rigid world-to-camera matrices [C,4,4] (what the reference keeps
+    as Camera.camera_center, camera_utils.py:51, and gsplat takes from inverse(viewmats))."""
+    lib = _lib.load()
+    viewmats = _req(viewmats, "viewmats")
+    out = torch.empty((viewmats.shape[0], 3), dtype=torch.float32, device=viewmats.device)
+    _lib.check(lib.sc_camera_centers(_p(viewmats), viewmats.shape[0], _p(out), _stream(viewmats)),
+               "sc_camera_centers")
+    return out
+
+
+_FUSED_RASTERIZATION = True
+
+
+def set_fused_rasterization(enabled: bool) -> bool:
+    """A/B switch for `rasterization()`'s fused forward (tests compare both); returns the old value."""
+    global _FUSED_RASTERIZATION
+    prev, _FUSED_RASTERIZATION = _FUSED_RASTERIZATION, bool(enabled)
+    return prev
+
+
+def _fused_forward_ok(tensors, sh_degree, render_mode, tile_size, colors) -> bool:
+    if not _FUSED_RASTERIZATION or sh_degree is None or render_mode not in ("RGB+D", "RGB+ED"):
+        return False
+    if tile_size != 16 or colors.dim() != 3 or colors.shape[-1] != 3:
+        return False
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return False         # the fused path is forward-only; training goes through the autograd operators
+    return True
+
+
+@torch.no_grad()
+def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane,
+                         far_plane, radius_clip, eps2d, sh_degree, tile_size, backgrounds, render_mode,
+                         antialiased, centers):
+    """a1 + a2 + a5 + a6 + a7 in one kernel, a3/a4 unchanged, a9 with the depth-normalising
+    epilogue of renderer.py:284 -- three operator-level launches and no torch elementwise kernels."""
+    lib = _lib.load()
+    means, quats, scales = _req(means, "means"), _req(quats, "quats"), _req(scales, "scales")
+    viewmats, Ks = _req(viewmats, "viewmats"), _req(Ks, "Ks")
+    opacities = _req(opacities, "opacities").reshape(-1)
+    colors = _req(colors, "colors")
+    C, N, K = viewmats.shape[0], means.shape[0], colors.shape[1]
+    assert opacities.shape[0] == N and colors.shape[0] == N, (opacities.shape, colors.shape)
+    dev = means.device
+    centers = camera_centers(viewmats) if centers is None else _req(centers, "camera_centers").reshape(C, 3)
+    radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+    means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+    depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+    conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+    opac = torch.empty((C, N), dtype=torch.float32, device=dev)
+    cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
+    st = _stream(means)
+    _lib.check(lib.sc_projection_sh_fwd(_p(means), _p(quats), _p(scales), _p(opacities), _p(colors), _p(viewmats),
+                                        _p(Ks), _p(centers), C, N, K, int(sh_degree), int(width), int(height),
+                                        float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+                                        int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
+                                        _p(opac), _p(cols), st), "sc_projection_sh_fwd")
+    tile_width = math.ceil(width / float(tile_size))
+    tile_height = math.ceil(height / float(tile_size))
+    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                          tile_height, packed=False, n_cameras=C)
+    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    if backgrounds is not None:
+        backgrounds = torch.cat([_req(backgrounds, "backgrounds"),
+                                 torch.zeros(C, 1, device=dev)], dim=-1).contiguous()
+    render_colors = torch.empty((C, height, width, 4), dtype=torch.float32, device=dev)
+    render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
+    ws = _ws(lib.sc_rasterize_workspace_bytes(C, N, 4), dev)
+    args = (_p(means2d), _p(conics), _p(cols), _p(opac), _p(backgrounds), None, C, N, 4, int(width), int(height),
+            int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+            _p(render_colors), _p(render_alphas))
+    if render_mode == "RGB+ED":
+        rc = lib.sc_rasterize_fwd_ed(*args, _p(ws), ws.numel(), st)
+        if rc == -3:          # a non-wave raster variant is selected: plain launch + the torch post-step
+            _lib.check(lib.sc_rasterize_fwd(*args, None, _p(ws), ws.numel(), st), "sc_rasterize_fwd")
+            render_colors = torch.cat([render_colors[..., :-1],
+                                       render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+        else:
+            _lib.check(rc, "sc_rasterize_fwd_ed")
+    else:
+        _lib.check(lib.sc_rasterize_fwd(*args, None, _p(ws), ws.numel(), st), "sc_rasterize_fwd")
+    meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+            "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+            "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+            "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "colors": cols,
+            "fused": True}
+    return render_colors, render_alphas, meta
+
+
 def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
                   viewmats: Tensor, Ks: Tensor, width: int, height: int, near_plane: float = 0.01,
                   far_plane: float = 1e10, radius_clip: float = 0.0, eps2d: float = 0.3,
@@ -463,17 +553,32 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                   backgrounds: Optional[Tensor] = None, render_mode: str = "RGB",
                   sparse_grad: bool = False, absgrad: bool = False, rasterize_mode: str = "classic",
                   channel_chunk: int = 32, distributed: bool = False, camera_model: str = "pinhole",
-                  covars: Optional[Tensor] = None):
-    """Composition of a1 -> a3 -> a4 -> a6 -> a9 with gsplat's `rasterization` signature.
-    means [N,3], quats [N,4], scales [N,3], opacities [N], colors [N,D] | [N,K,3] (with sh_degree),
-    viewmats [C,4,4], Ks [C,3,3].  Returns (render_colors [C,H,W,*], render_alphas [C,H,W,1], meta)."""
+                  covars: Optional[Tensor] = None, camera_centers_: Optional[Tensor] = None):
+    """gsplat's one-call API (imported at renderer.py:204).  means [N,3], quats [N,4], scales [N,3],
+    opacities [N], colors [N,D] | [N,K,3] (with sh_degree), viewmats [C,4,4], Ks [C,3,3].  Returns
+    (render_colors [C,H,W,*], render_alphas [C,H,W,1], meta).
+
+    With `sh_degree` set, `render_mode` "RGB+D"/"RGB+ED" and no gradient required -- i.e. exactly what
+    render_kernel_gsplat (renderer.py:186-302) spells out by hand: sh_degree=max_sh_degree,
+    rasterize_mode="antialiased", render_mode="RGB+ED" -- the forward runs FUSED (see
+    _rasterization_fused); results are bit-identical to the composition a1 -> a3 -> a4 -> a6 -> a9 below,
+    which remains the path for training and for every other mode.
+    `camera_centers_` (not in gsplat): optional precomputed [C,3] camera positions, e.g. the reference's
+    Camera.camera_center; by default they are derived from `viewmats` (rigid inverse)."""
     assert render_mode in ("RGB", "D", "ED", "RGB+D", "RGB+ED"), render_mode
     assert rasterize_mode in ("classic", "antialiased"), rasterize_mode
     if camera_model != "pinhole" or distributed or covars is not None:
         raise NotImplementedError("only pinhole, single-process, quats/scales input is supported")
+    if packed:
+        raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
     C = viewmats.shape[0]
     N = means.shape[0]
     aa = rasterize_mode == "antialiased"
+    if _fused_forward_ok((means, quats, scales, opacities, colors, viewmats, Ks, backgrounds), sh_degree,
+                         render_mode, tile_size, colors):
+        return _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, width, height,
+                                    near_plane, far_plane, radius_clip, eps2d, sh_degree, tile_size,
+                                    backgrounds, render_mode, aa, camera_centers_)
     radii, means2d, depths, conics, comps = fully_fused_projection(
         means, None, quats, scales, viewmats, Ks, width, height, eps2d=eps2d, near_plane=near_plane,
         far_plane=far_plane, radius_clip=radius_clip, calc_compensations=aa)
@@ -488,7 +593,7 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
     if sh_degree is None:
         cols = colors.reshape(1, N, -1).expand(C, N, -1) if colors.dim() == 2 else colors
     else:
-        campos = torch.linalg.inv(viewmats)[:, :3, 3]
+        campos = camera_centers(viewmats) if camera_centers_ is None else camera_centers_.reshape(C, 3)
         dirs = means[None, :, :] - campos[:, None, :]
         shs = colors.reshape(1, N, -1, 3).expand(C, N, -1, 3)
         cols = spherical_harmonics(sh_degree, dirs, shs, masks=radii > 0)
@@ -510,5 +615,6 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
     meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
             "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
             "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
-            "width": width, "height": height, "tile_size": tile_size, "n_cameras": C}
+            "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "colors": cols,
+            "fused": False}
     return render_colors, render_alphas, meta

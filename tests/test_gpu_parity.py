@@ -528,6 +528,76 @@ def test_train_mode_contract_retain_grad_and_absgrad(ops):
     assert float(sc.means.grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("render_mode,rasterize_mode,deg,use_bg", [
+    ("RGB+ED", "antialiased", 1, False),     # what render_kernel_gsplat spells out by hand
+    ("RGB+ED", "classic", 3, True),
+    ("RGB+D", "antialiased", 0, False),
+])
+def test_rasterization_fused_matches_composition(ops, render_mode, rasterize_mode, deg, use_bg):
+    """gsplat's one-call `rasterization()` runs a fused forward (projection + opacity
+    compensation + SH + clamp + depth channel in one kernel, depth normalisation in the rasterizer's
+    epilogue).  It must be BIT-identical to the composition of the separate operators + torch glue."""
+    from street_crafter_amd import rendering
+    sc = make_scene(30_000, sh_degree=deg, seed=11, z_range=(1.0, 60.0)).to(DEV)
+    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.1 * i, shift=(0.3 * i, 0.0, -0.5 * i)) for i in range(2)]
+    V = torch.stack([c.viewmat for c in cams]).to(DEV)
+    K = torch.stack([c.K for c in cams]).to(DEV)
+    bg = torch.rand(2, 3, device=DEV) if use_bg else None
+    kw = dict(near_plane=0.001, far_plane=1000.0, sh_degree=deg, render_mode=render_mode,
+              rasterize_mode=rasterize_mode, backgrounds=bg)
+    outs = []
+    for fused in (True, False):
+        prev = rendering.set_fused_rasterization(fused)
+        try:
+            with torch.no_grad():
+                outs.append(ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, V, K,
+                                              640, 400, **kw))
+        finally:
+            rendering.set_fused_rasterization(prev)
+    (rc_f, ra_f, m_f), (rc_c, ra_c, m_c) = outs
+    assert m_f["fused"] and not m_c["fused"]
+    assert float(ra_f.sum()) > 0
+    np.testing.assert_array_equal(_np(rc_f).view(np.uint32), _np(rc_c).view(np.uint32))
+    np.testing.assert_array_equal(_np(ra_f).view(np.uint32), _np(ra_c).view(np.uint32))
+    for key in ("radii", "means2d", "depths", "conics", "opacities", "colors", "isect_ids", "flatten_ids",
+                "isect_offsets", "tiles_per_gauss"):
+        a, b = _np(m_f[key]), _np(m_c[key])
+        assert a.shape == b.shape, key
+        np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8), err_msg=key)
+
+
+def test_rasterization_fused_equals_reference_caller_sequence(ops):
+    """The fused one-call path against the caller's hand-written sequence (pipeline.render_gaussians =
+    renderer.py:186-302) on the same camera, camera centre taken from the Camera as the reference does."""
+    from street_crafter_amd.pipeline import render_gaussians
+    sc = make_scene(50_000, seed=5).to(DEV)
+    cam = make_camera(800, 528, 2050.0 * 800 / 1920, 2050.0 * 800 / 1920).to(DEV)
+    with torch.no_grad():
+        ref = render_gaussians(sc, cam, mode="eval", return_intermediates=True)
+        rc, ra, meta = ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, cam.viewmat[None],
+                                         cam.K[None], cam.width, cam.height, near_plane=cam.znear,
+                                         far_plane=cam.zfar, sh_degree=sc.sh_degree, render_mode="RGB+ED",
+                                         rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
+    assert meta["fused"]
+    np.testing.assert_array_equal(_np(rc[0, ..., :3].clamp(0.0, 1.0).permute(2, 0, 1)).view(np.uint32),
+                                  _np(ref["rgb"]).view(np.uint32))
+    np.testing.assert_array_equal(_np(rc[0, ..., 3]).view(np.uint32), _np(ref["depth"][0]).view(np.uint32))
+    np.testing.assert_array_equal(_np(ra[0, ..., 0]).view(np.uint32), _np(ref["acc"][0]).view(np.uint32))
+    np.testing.assert_array_equal(_np(meta["radii"]), _np(ref["_radii"]))
+
+
+def test_rasterization_falls_back_to_autograd_operators_when_training(ops):
+    sc = make_scene(3000, seed=6, z_range=(1.0, 30.0), scale_range=(0.02, 0.3)).to(DEV)
+    cam = make_camera(160, 96, 180.0, 180.0).to(DEV)
+    sc.means.requires_grad_(True)
+    rc, ra, meta = ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, cam.viewmat[None],
+                                     cam.K[None], 160, 96, near_plane=0.001, far_plane=1000.0, sh_degree=1,
+                                     render_mode="RGB+ED", rasterize_mode="antialiased", absgrad=True)
+    assert not meta["fused"]
+    (rc.sum() + ra.sum()).backward()
+    assert sc.means.grad is not None and torch.isfinite(sc.means.grad).all() and float(sc.means.grad.abs().sum()) > 0
+
+
 def test_densification_statistics_consumer_vs_oracle(ops):
     """what train.py:283-284 reads after backward -- means2d.grad (non-leaf, retain_grad),
     means2d.absgrad (attribute set by the rasterizer's backward), visibility_filter and radii -- fed to
