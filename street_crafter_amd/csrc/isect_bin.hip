@@ -39,7 +39,8 @@ constexpr int BIN_GPT = 4;                       // gaussians per thread in the 
 constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
 constexpr int SCAT_THREADS = 256;
 constexpr int BIN_MAX_TILES = 16384;             // C * tile_width * tile_height handled by this path
-constexpr int BIN_BIG = 64;                      // rectangles larger than this are walked by a whole wave
+constexpr int BIN_BIG = 32;                      // rectangles larger than this are walked by a whole wave
+                                                 // (A/B on S-1M: 4 -> 86 us, 8 -> 76, 16 -> 69, 32 -> 69, 64 -> 77)
 constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
 constexpr unsigned long long KEY_MASK = 0xffffffff0fffffffull;   // (depth, id) without the tile mask
 
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 // (dy << ss | dx) set when tile (2sx+dx, 2sy+dy) lies inside the Gaussian's tile rectangle.
 template <typename F>
 __device__ __forceinline__ void walk_super(const Rect& r, bool live, int cam_base, const Geo& g,
-                                           unsigned depth, unsigned id, F&& f) {
+                                           unsigned depth, unsigned id, int big_thresh, F&& f) {
     const Rect s = live ? super_rect(r, g.ss) : Rect{0, 0, 0, 0};
     const int sw = s.x1 - s.x0, cnt = sw * (s.y1 - s.y0);
     auto mask_of = [&](int x0, int x1, int y0, int y1, int sx, int sy) -> unsigned {
@@ -289,12 +290,12 @@ __device__ __forceinline__ void walk_super(const Rect& r, bool live, int cam_bas
         if (ty + 1 >= y0 && ty + 1 < y1) { if (tx >= x0 && tx < x1) m |= 4u; if (tx + 1 >= x0 && tx + 1 < x1) m |= 8u; }
         return m;
     };
-    if (cnt > 0 && cnt <= BIN_BIG) {
+    if (cnt > 0 && cnt <= big_thresh) {
         for (int sy = s.y0; sy < s.y1; ++sy)
             for (int sx = s.x0; sx < s.x1; ++sx)
                 f(cam_base + sy * g.stw + sx, mask_of(r.x0, r.x1, r.y0, r.y1, sx, sy), depth, id);
     }
-    unsigned long long big = __ballot(cnt > BIN_BIG);
+    unsigned long long big = __ballot(cnt > big_thresh);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
+    const int big_thresh = (dbg >> 8) ? (dbg >> 8) : BIN_BIG;      // tuning knob in debug0's upper bits
     const int64_t M = n_visible[0];
     constexpr int SCAT_GPB = SCAT_THREADS * SCAT_GPT;
     const int64_t base = (int64_t)blockIdx.x * SCAT_GPB;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
             dd[k] = __float_as_uint(depths[i]);
             ii[k] = (unsigned)i;
         }
-        walk_super(rr[k], live[k], cb[k], g, 0u, 0u,
+        walk_super(rr[k], live[k], cb[k], g, 0u, 0u, big_thresh,
                    [&](int b, unsigned, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     }
     __syncthreads();
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
     if (dbg & 2) return;
 #pragma unroll
     for (int k = 0; k < SCAT_GPT; ++k) {
-        walk_super(rr[k], live[k], cb[k], g, dd[k], ii[k], [&](int b, unsigned mask, unsigned d, unsigned id) {
+        walk_super(rr[k], live[k], cb[k], g, dd[k], ii[k], big_thresh, [&](int b, unsigned mask, unsigned d, unsigned id) {
             const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
             if (!(dbg & 1)) records[slot] = make_uint2(d, id | (mask << 28));
         });
