@@ -235,13 +235,27 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(ScanJobs jobs) {
 }
 
 // ---- spatial order: counting sort of the visible Gaussians by centre super-tile --------------------
+// The host needs meta (the output sizes) once per frame.  Instead of a D2H copy + event on the stream
+// (a copy kernel plus a ~6 us barrier bubble between the count and the scatter kernels), one lane
+// stores the four numbers straight into host-mapped pinned memory, then a sequence number with
+// system-scope release; the host polls the sequence number.
+__device__ __forceinline__ void publish_meta(const int64_t* __restrict__ meta_dev, int64_t* mirror, int64_t seq) {
+    mirror[0] = meta_dev[0]; mirror[1] = meta_dev[1]; mirror[2] = meta_dev[2]; mirror[3] = meta_dev[3];
+    __hip_atomic_store(&mirror[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_t* mirror, int64_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
-    const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor, int32_t* __restrict__ perm) {
+    const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor, int32_t* __restrict__ perm,
+    const int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
     extern __shared__ unsigned lds[];
     unsigned* hist = lds;                // [n_sbuckets]
     unsigned* gbase = lds + n_sbuckets;  // [n_sbuckets]
+    if (meta_mirror && blockIdx.x == 0 && threadIdx.x == 0) publish_meta(meta_dev, meta_mirror, seq);
     for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) hist[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
@@ -673,13 +687,16 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 
 // ---- host side --------------------------------------------------------------------------------
 // count-phase workspace (handed to BOTH calls):
-//   dgrid_t | dgrid_s | chist | ccursor | soffsets | cstart | smeta[2] | cmeta[2] | perm[CN]
+//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | soffsets | cstart | smeta[2] | cmeta[2] | perm[CN]
+//   (everything before soffsets is zeroed by the ONE memset of a frame; rcursor / rflags are the
+//    scatter's bucket cursors and the "needs the radix fallback" flags of the sort phase, kept here so
+//    that the sort phase needs no memset of its own: a second memset cost 5 us + a 6 us bubble)
 // sort-phase workspace:
-//   cursor[nsb] | needs_radix[nsb] | records uint2[rec_capacity]
+//   records uint2[rec_capacity]
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
-    size_t dgrid_t, dgrid_s, chist, ccursor, soffsets, cstart, smeta, cmeta, perm, total;
+    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, soffsets, cstart, smeta, cmeta, perm, total;
 };
 
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
@@ -699,6 +716,8 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.dgrid_s = take((size_t)L.ns_cells * 4);
     L.chist = take((size_t)L.nsb * 4);
     L.ccursor = take((size_t)L.nsb * 4);
+    L.rcursor = take((size_t)L.nsb * 4);
+    L.rflags = take((size_t)L.nsb);
     L.soffsets = take((size_t)L.nsb * 4);
     L.cstart = take((size_t)L.nsb * 4);
     L.smeta = take(16);
@@ -718,13 +737,13 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
     if (nb <= 0 || nb > BIN_MAX_TILES) return 256;
     const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
     if (n_isects < 0) return L.total;                                  // count-phase workspace
-    return 2 * sc_align_up((size_t)L.nsb * 4, 256) + sc_align_up((size_t)n_isects * 8, 256) + 256;
+    return sc_align_up((size_t)n_isects * 8, 256) + 256;
 }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N, int tile_size,
                                   int tile_width, int tile_height, int32_t* tiles_per_gauss,
-                                  int32_t* isect_offsets, int64_t* meta_dev, void* count_workspace,
-                                  size_t ws_bytes, sc_stream_t stream) {
+                                  int32_t* isect_offsets, int64_t* meta_dev, int64_t* meta_mirror,
+                                  int64_t seq, void* count_workspace, size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (!meta_dev) return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
@@ -733,7 +752,12 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     hipStream_t s = sc_s(stream);
     if (CN == 0 || nb64 == 0) {
         if (nb64 > 0 && isect_offsets) SC_HIP(hipMemsetAsync(isect_offsets, 0, (size_t)nb64 * 4, s));
-        return (int)hipMemsetAsync(meta_dev, 0, 4 * sizeof(int64_t), s);
+        SC_HIP(hipMemsetAsync(meta_dev, 0, 4 * sizeof(int64_t), s));
+        if (meta_mirror) {
+            hipLaunchKernelGGL(publish_meta_kernel, dim3(1), dim3(64), 0, s, (const int64_t*)meta_dev, meta_mirror, seq);
+            SC_LAUNCH_CHECK();
+        }
+        return SC_OK;
     }
     if (!means2d || !radii || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
     const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
@@ -748,7 +772,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     int32_t* cstart = (int32_t*)(ws + L.cstart);
     int64_t* cmeta = (int64_t*)(ws + L.cmeta);
     int32_t* perm = (int32_t*)(ws + L.perm);
-    SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor
+    SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
@@ -769,7 +793,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)L.nsb * 8, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
-                       (const int32_t*)cstart, ccursor, perm);
+                       (const int32_t*)cstart, ccursor, perm, (const int64_t*)meta_dev, meta_mirror, seq);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
@@ -777,7 +801,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
 extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C,
                                  int N, int tile_size, int tile_width, int tile_height,
                                  const int32_t* isect_offsets, const int64_t* meta_dev,
-                                 const void* count_workspace, int64_t capacity, int64_t rec_capacity,
+                                 void* count_workspace, int64_t capacity, int64_t rec_capacity,
                                  int64_t super_capacity, int64_t* isect_ids, int32_t* flatten_ids,
                                  void* workspace, size_t ws_bytes, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0 || capacity < 0 ||
@@ -797,16 +821,15 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     if (ws_bytes < sc_isect_bin_workspace_bytes(CN, C, tile_width, tile_height, rec_capacity)) return SC_EWORKSPACE;
     hipStream_t s = sc_s(stream);
     const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
-    const unsigned char* cws = (const unsigned char*)count_workspace;
+    unsigned char* cws = (unsigned char*)count_workspace;
     const int32_t* soffsets = (const int32_t*)(cws + L.soffsets);
     const int64_t* cmeta = (const int64_t*)(cws + L.cmeta);
     const int32_t* perm = (const int32_t*)(cws + L.perm);
-    unsigned char* ws = (unsigned char*)workspace;
-    const size_t nsb_bytes = sc_align_up((size_t)L.nsb * 4, 256);
-    unsigned* cursor = (unsigned*)ws;
-    unsigned char* needs_radix = ws + nsb_bytes;
-    uint2* records = (uint2*)(ws + 2 * nsb_bytes);
-    SC_HIP(hipMemsetAsync(ws, 0, 2 * nsb_bytes, s));   // cursor + needs_radix flags
+    // zero since sc_isect_bin_count; consumed by the one launch whose capacities pass the device-side
+    // check (kernels of a launch with too small capacities return before touching them)
+    unsigned* cursor = (unsigned*)(cws + L.rcursor);
+    unsigned char* needs_radix = cws + L.rflags;
+    uint2* records = (uint2*)workspace;
 #define SC_LAUNCH_SCATTER(GPT)                                                                               \
     hipLaunchKernelGGL(bin_scatter_kernel<GPT>, dim3((unsigned)((CN + SCAT_THREADS * GPT - 1) / (SCAT_THREADS * GPT))), \
                        dim3(SCAT_THREADS), (size_t)L.nsb * 8, s, means2d, radii, depths, perm, cmeta, L.g,          \

@@ -10,6 +10,7 @@ There is no CPU path: non-HIP tensors raise.
 from __future__ import annotations
 
 import math
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -210,7 +211,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
-_PINNED_META = {}      # device index -> pinned int64[4] used for the one D2H read per frame
+_PINNED_META = {}      # device index -> [pinned int64[8] the device publishes meta into, its numpy view, seq]
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
@@ -219,18 +220,36 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
     meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
     ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
+    # meta (output sizes) comes back through host-mapped pinned memory that the device writes
+    # directly, followed by a sequence number: no D2H copy and no event on the stream (include/*.h)
+    slot = _PINNED_META.get(dev.index)
+    if slot is None:
+        host = torch.zeros(8, dtype=torch.int64, pin_memory=True)
+        slot = _PINNED_META[dev.index] = [host, host.numpy(), 0]
+    meta_host, meta_np = slot[0], slot[1]
+    slot[2] += 1
+    seq = slot[2]
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
-                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev), _p(ws0),
-                                ws0.numel(), st)
+                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
+                                meta_host.data_ptr(), seq, _p(ws0), ws0.numel(), st)
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
     _lib.check(rc, "sc_isect_bin_count")
-    meta_host = _PINNED_META.get(dev.index)
-    if meta_host is None:
-        meta_host = _PINNED_META[dev.index] = torch.empty(4, dtype=torch.int64, pin_memory=True)
-    meta_host.copy_(meta_dev, non_blocking=True)
-    ready = torch.cuda.Event()
-    ready.record()
+
+    def read_meta():
+        # poll the sequence number; if the GPU is far behind (or something went wrong) fall back to a
+        # plain synchronising copy after ~2 s
+        deadline = None
+        spins = 0
+        while meta_np[4] != seq:
+            spins += 1
+            if spins % 4096 == 0:
+                now = time.monotonic()
+                if deadline is None:
+                    deadline = now + 2.0
+                elif now > deadline:
+                    return tuple(int(v) for v in meta_dev.cpu().tolist())
+        return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
     def launch(capacity, rec_capacity, super_capacity):
         ids = torch.empty(capacity, dtype=torch.int64, device=dev)
@@ -250,8 +269,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             rc = None
         elif rc != 0:
             _lib.check(rc, "sc_isect_bin_sort")
-    ready.synchronize()        # the one D2H read of a frame (sizes the outputs); GPU already has work
-    n_isects, _, n_records, max_super = (int(v) for v in meta_host.tolist())
+    n_isects, _, n_records, max_super = read_meta()     # the one host wait of a frame; GPU already has work
     if rc is None or n_isects > pred[0] or n_records > pred[1] or max_super > pred[2]:
         rc, ids, fids = launch(n_isects, n_records, max_super)
         if rc == -3:
