@@ -22,6 +22,7 @@
 // alpha moves by ~2e-6 (relative); pixels stay within the 1e-4 bar of the parity tests.
 // Opacity <= 0 (or NaN) gives alpha = 0 / NaN and the splat is skipped (alpha >= 1/255 is false).
 struct ScSplat { float mx, my, A2, B2, C2, lop; };
+typedef float sc_f2 __attribute__((ext_vector_type(2)));      // pixel pairs for the packed-fp32 VALU ops
 
 __device__ __forceinline__ ScSplat sc_prescale(float mx, float my, float a, float b, float c, float op) {
     ScSplat s;

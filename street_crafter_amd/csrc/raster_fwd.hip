@@ -511,16 +511,33 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
     const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
 
-    float T[4] = {1.f, 1.f, 1.f, 1.f};
+    // Per-pixel state in PAIRS (v_pk_add / v_pk_fma / v_pk_mul process two pixels per VALU op; the blend
+    // loop is VALU-bound).  A finished pixel (terminated, or outside the image) is marked by poisoning
+    // its x coordinate with +inf: dx = -inf, sigma2 = +inf, alpha = exp2(-inf) = 0 < 1/255, so it can
+    // never blend again and the loop needs no per-pixel `done` flag or mask bookkeeping at all.
+    // (A2 == 0 would turn that into 0 * inf = NaN, hence the staging replaces an exactly-zero A2 by
+    // 1e-37, which no finite pixel can see: 1e-37 * dx^2 is absorbed by every other term.)
+    const float INF = __builtin_huge_valf();
+    sc_f2 pxp[2], T2[2];
     int cur[4] = {0, 0, 0, 0};
-    bool done[4];
     float acc[4][CDIM];
 #pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        pxp[p] = sc_f2{inside[2 * p] ? pxf[2 * p] : INF, inside[2 * p + 1] ? pxf[2 * p + 1] : INF};
+        T2[p] = sc_f2{1.f, 1.f};
+    }
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        done[k] = !inside[k];
 #pragma unroll
         for (int d = 0; d < CDIM; ++d) acc[k][d] = 0.f;
     }
+    // x coordinates are positive floats or +inf, so their bit patterns order like integers
+    // (integer min: no NaN canonicalisation ops)
+    auto all_done = [&]() -> bool {
+        const int m = min(min(__float_as_int(pxp[0].x), __float_as_int(pxp[0].y)),
+                          min(__float_as_int(pxp[1].x), __float_as_int(pxp[1].y)));
+        return __all(m == 0x7f800000);
+    };
 
     // register-staged pipeline: parameters of batch b, ids of batch b+1
     float2 p_xy[SB];
@@ -561,7 +578,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     }
 
     for (int b = 0; b < num_batches; ++b) {
-        if (__all(done[0] && done[1] && done[2] && done[3])) break;
+        if (all_done()) break;
         const int batch_start = range_start + B * b;
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
         int bsz = 0;
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             if (keep) {
                 const int slot = bsz + __popcll(m & sc_lanemask_lt());
                 const ScSplat sp = sc_prescale(p_xy[j].x, p_xy[j].y, p_a[j], p_b[j], p_c[j], p_op[j]);
-                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
+                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2 == 0.f ? 1e-37f : sp.A2);
                 bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(batch_start + j * 64 + lane), 0.f);
                 col_s[slot] = p_col[j];
             }
@@ -601,30 +618,42 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
                 const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the 4 pixels
                 const int sidx = __float_as_int(bc.z);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dx = a.x - pxf[k];
-                    const float sigma = sc_sigma2(a.w, bdy, qdy, dx);
-                    const float alpha = sc_alpha2(a.z, sigma);
-                    const bool valid = !done[k] && sc_valid(sigma, alpha);
-                    const float next_T = sc_next_T(T[k], alpha);
-                    const bool term = valid && (next_T <= SC_T_EPS);
-                    done[k] = done[k] || term;
-                    const bool blend = valid && !term;
-                    const float a_eff = blend ? alpha : 0.f;      // one select drives vis AND the T update
-                    const float vis = __fmul_rn(a_eff, T[k]);
+                for (int p = 0; p < 2; ++p) {
+                    // the pinned arithmetic of raster_common.h, two pixels per instruction
+                    const sc_f2 dx = sc_f2{a.x, a.x} - pxp[p];
+                    const sc_f2 tt = __builtin_elementwise_fma(sc_f2{a.w, a.w}, dx, sc_f2{bdy, bdy});
+                    const sc_f2 sg = __builtin_elementwise_fma(tt, dx, sc_f2{qdy, qdy});
+                    const sc_f2 e = sc_f2{a.z, a.z} - sg;
+                    const sc_f2 al = sc_f2{fminf(SC_ALPHA_MAX, __builtin_amdgcn_exp2f(e.x)),
+                                           fminf(SC_ALPHA_MAX, __builtin_amdgcn_exp2f(e.y))};
+                    const bool v0 = sc_valid(sg.x, al.x), v1 = sc_valid(sg.y, al.y);
+                    const sc_f2 nT = __builtin_elementwise_fma(-al, T2[p], T2[p]);
+                    const bool t0 = v0 && (nT.x <= SC_T_EPS), t1 = v1 && (nT.y <= SC_T_EPS);
+                    const bool b0 = v0 && !t0, b1 = v1 && !t1;
+                    const sc_f2 ae = sc_f2{b0 ? al.x : 0.f, b1 ? al.y : 0.f};   // one select drives vis AND T
+                    const sc_f2 vis = ae * T2[p];
+                    T2[p] = __builtin_elementwise_fma(ae, -T2[p], T2[p]);       // == nT when blending, else T
+                    pxp[p] = sc_f2{t0 ? INF : pxp[p].x, t1 ? INF : pxp[p].y};
                     // adding c*0 leaves the sums bit-identical to skipping (sums are never -0)
-                    acc[k][0] = __fmaf_rn(c.x, vis, acc[k][0]);
-                    acc[k][1] = __fmaf_rn(c.y, vis, acc[k][1]);
-                    acc[k][2] = __fmaf_rn(c.z, vis, acc[k][2]);
-                    if (CDIM > 3) acc[k][3] = __fmaf_rn(c.w, vis, acc[k][3]);
-                    if (TRACK) cur[k] = blend ? sidx : cur[k];
-                    T[k] = sc_next_T(T[k], a_eff);                // == next_T when blending, == T[k] otherwise
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float vh = h ? vis.y : vis.x;
+                        acc[2 * p + h][0] = __fmaf_rn(c.x, vh, acc[2 * p + h][0]);
+                        acc[2 * p + h][1] = __fmaf_rn(c.y, vh, acc[2 * p + h][1]);
+                        acc[2 * p + h][2] = __fmaf_rn(c.z, vh, acc[2 * p + h][2]);
+                        if (CDIM > 3) acc[2 * p + h][3] = __fmaf_rn(c.w, vh, acc[2 * p + h][3]);
+                    }
+                    if (TRACK) {
+                        cur[2 * p] = b0 ? sidx : cur[2 * p];
+                        cur[2 * p + 1] = b1 ? sidx : cur[2 * p + 1];
+                    }
                 }
-                if (__all(done[0] && done[1] && done[2] && done[3])) break;
+                if (all_done()) break;
                 a = an; bc = bcn; c = cn;
             }
         }
     }
+    const float T[4] = {T2[0].x, T2[0].y, T2[1].x, T2[1].y};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (!inside[k]) continue;
