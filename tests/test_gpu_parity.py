@@ -657,6 +657,49 @@ def test_densification_statistics_consumer_vs_oracle(ops):
         assert np.isfinite(g_abs).all()
 
 
+def test_scene_files_drive_the_renderer(ops, tmp_path):
+    """a scene written in the reference's PLY layout (background + a posed actor with Fourier
+    colour), read back and composed, renders bit-identically to the in-memory composition; and an actor
+    under pose (q, t) renders exactly like the same Gaussians moved by hand into the background."""
+    from street_crafter_amd import scene_io as sio
+    from street_crafter_amd.pipeline import render_gaussians
+    bk = sio.scene_to_submodel(make_scene(8000, seed=8, z_range=(4.0, 40.0)))
+    g = torch.Generator().manual_seed(2)
+    n = 1500
+    act = sio.SubModel(name="obj_007", xyz=torch.randn(n, 3, generator=g) * torch.tensor([1.0, 0.6, 2.0]),
+                       features_dc=torch.randn(n, 5, 3, generator=g), features_rest=torch.randn(n, 3, 3, generator=g) * 0.2,
+                       scaling=torch.randn(n, 3, generator=g) * 0.3 - 2.5, rotation=torch.randn(n, 4, generator=g),
+                       opacity=torch.randn(n, 1, generator=g) + 1.0, start_frame=0, end_frame=40)
+    q = torch.tensor([math.cos(0.3), 0.0, math.sin(0.3), 0.0])
+    t = torch.tensor([0.5, 0.2, 12.0])
+    path = str(tmp_path / "point_cloud.ply")
+    sio.write_ply(path, [bk, act])
+    cam = make_camera(640, 400, 600.0, 600.0).to(DEV)
+    mem = sio.compose_scene({"background": bk, "obj_007": act}, {"obj_007": (q, t)}, frame=10.0, device=DEV)
+    fil = sio.compose_scene(sio.read_ply(path), {"obj_007": (q, t)}, frame=10.0, device=DEV)
+    # the file does not carry the actor's frame range: set it as the scene metadata would
+    assert fil.graph_gaussian_range == mem.graph_gaussian_range == {"background": (0, 8000), "obj_007": (8000, 9500)}
+    with torch.no_grad():
+        a = render_gaussians(mem.scene, cam)
+        fil_models = sio.read_ply(path)
+        fil_models["obj_007"].start_frame, fil_models["obj_007"].end_frame = 0, 40
+        b = render_gaussians(sio.compose_scene(fil_models, {"obj_007": (q, t)}, frame=10.0, device=DEV).scene, cam)
+    assert float(a["acc"].sum()) > 0
+    for k in ("rgb", "acc", "depth"):
+        np.testing.assert_array_equal(_np(a[k]).view(np.uint32), _np(b[k]).view(np.uint32))
+    # the posed actor against the same Gaussians transformed by hand
+    R = sio.quaternion_to_matrix(q[None])[0]
+    moved = sio.SubModel(name="background", xyz=torch.cat([bk.xyz, act.xyz @ R.T + t]),
+                         features_dc=torch.cat([bk.features_dc, sio.actor_features(act, 10.0)[:, :1]]),
+                         features_rest=torch.cat([bk.features_rest, act.features_rest]),
+                         scaling=torch.cat([bk.scaling, act.scaling]),
+                         rotation=torch.cat([bk.rotation, sio.quaternion_raw_multiply(q[None], torch.nn.functional.normalize(act.rotation))]),
+                         opacity=torch.cat([bk.opacity, act.opacity]))
+    with torch.no_grad():
+        c = render_gaussians(sio.compose_scene({"background": moved}, device=DEV).scene, cam)
+    assert _rel_err(_np(c["rgb"]), _np(a["rgb"])) < 1e-5
+
+
 # ---- knn ------------------------------------------------------------------------------------------
 def test_knn_golden_bit_exact(golden_dir):
     from simple_knn._C import distCUDA2

@@ -27,8 +27,12 @@ REF = "/root/reference"
 
 def ref_vectors():
     sys.path.insert(0, REF)
-    from street_gaussian.utils.sh_utils import eval_sh          # noqa: E402
+    from street_gaussian.utils.sh_utils import eval_sh, IDFT    # noqa: E402
     from street_gaussian.utils.loss_utils import psnr           # noqa: E402
+    # the actors' Fourier colour basis (consumed by street_crafter_amd/scene_io.py)
+    times = torch.tensor([0.0, 0.125, 0.5, 0.77, 1.0, 2.5])
+    np.savez_compressed(os.path.join(GOLD, "idft_ref.npz"), times=times.numpy(),
+                        dim5=IDFT(times, 5).numpy(), dim8=IDFT(times, 8).numpy(), dim1=IDFT(times, 1).numpy())
     g = torch.Generator().manual_seed(11)
     n = 512
     d = torch.randn(n, 3, generator=g, dtype=torch.float64)
