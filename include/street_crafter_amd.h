@@ -108,14 +108,14 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
  * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384, C*N >= 2^28 or
  * super_capacity > 7168; the caller then takes the count/emit/radix-sort route.
  */
-/* n_records < 0: bytes of the count-phase workspace (shared by both calls; holds the spatial order
- * of the visible Gaussians); n_records >= 0: bytes of the sort-phase workspace for that many records. */
+/* n_records < 0: bytes of the count-phase workspace (shared by both calls; holds the visible Gaussians'
+ * rectangle / depth / id, 16 B each, in spatial order); n_records >= 0: bytes of the sort-phase workspace for that many records. */
 size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height, int64_t n_records);
 /* meta_mirror (nullable): HOST-MAPPED pinned int64[5] (hipHostMalloc; torch pin_memory).  When given,
  * the device stores meta[0..3] there and then `seq` into meta_mirror[4] with system-scope release, so
  * the host can poll meta_mirror[4] == seq instead of enqueuing a D2H copy + event (which costs a copy
  * kernel and a barrier bubble in the middle of the frame). */
-int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N,
+int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                        int tile_size, int tile_width, int tile_height,
                        int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* meta_dev /* [4] */,
                        int64_t* meta_mirror /* [5], nullable */, int64_t seq,

@@ -41,7 +41,7 @@ SIGNATURES = {
     "sc_radix_sort_pairs_u64_i32": (C.c_int, [c_u64p, c_i32p, c_u64p, c_i32p, C.c_int64, C.c_int,
                                               C.c_void_p, C.c_size_t, c_stream]),
     "sc_isect_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]),
-    "sc_isect_bin_count": (C.c_int, [c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
+    "sc_isect_bin_count": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
                                      c_i32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, C.c_size_t, c_stream]),
     "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_i32p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i64p,

@@ -39,10 +39,8 @@ constexpr int BIN_GPT = 4;                       // gaussians per thread in the 
 constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
 constexpr int CNT_GPT = 8;                       // ... and in the count pass, whose cost is the flush of the
 constexpr int CNT_GPB = BIN_THREADS * CNT_GPT;   // per-workgroup grids (A/B on S-1M: 2 -> 36 us, 4 -> 23, 8 -> 19, 16 -> 25)
-constexpr int SCAT_THREADS = 256;
 constexpr int BIN_MAX_TILES = 16384;             // C * tile_width * tile_height handled by this path
 constexpr int BIN_BIG = 32;                      // rectangles larger than this are walked by a whole wave
-                                                 // (A/B on S-1M: 4 -> 86 us, 8 -> 76, 16 -> 69, 32 -> 69, 64 -> 77)
 constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
 constexpr unsigned long long KEY_MASK = 0xffffffff0fffffffull;   // (depth, id) without the tile mask
 
@@ -252,8 +250,8 @@ __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_
 __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
-    const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor, int32_t* __restrict__ perm,
-    const int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
+    const float* __restrict__ depths, const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor,
+    uint4* __restrict__ sorted, const int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
     extern __shared__ unsigned lds[];
     unsigned* hist = lds;                // [n_sbuckets]
     unsigned* gbase = lds + n_sbuckets;  // [n_sbuckets]
@@ -262,10 +260,12 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
     int cb[BIN_GPT];
+    uint4 pay[BIN_GPT];      // tile rectangle (x0 | x1 << 16, y0 | y1 << 16), depth bits, flat id
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
         const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
         cb[k] = -1;
+        pay[k] = make_uint4(0u, 0u, 0u, 0u);
         if (i < CN && tiles_per_gauss[i] > 0) {
             const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
             const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
@@ -273,6 +273,8 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
             cb[k] = (int)(i / g.N) * g.ST + cy * g.stw + cx;
             atomicAdd(&hist[cb[k]], 1u);
+            pay[k] = make_uint4((unsigned)r.x0 | ((unsigned)r.x1 << 16), (unsigned)r.y0 | ((unsigned)r.y1 << 16),
+                                __float_as_uint(depths[i]), (unsigned)i);
         }
     }
     __syncthreads();
@@ -285,106 +287,138 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < BIN_GPT; ++k) {
         const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
-        if (cb[k] >= 0) perm[gbase[cb[k]] + atomicAdd(&hist[cb[k]], 1u)] = (int32_t)i;
+        if (cb[k] >= 0) sorted[gbase[cb[k]] + atomicAdd(&hist[cb[k]], 1u)] = pay[k];
     }
 }
 
-// ---- pass 2: records ------------------------------------------------------------------------------
-// Calls f(bucket, mask, depth, id) for every super-tile of this lane's super rectangle; rectangles
-// with more than BIN_BIG super-tiles are spread over the 64 lanes of the wave.  `mask` has bit
-// (dy << ss | dx) set when tile (2sx+dx, 2sy+dy) lies inside the Gaussian's tile rectangle.
-template <typename F>
-__device__ __forceinline__ void walk_super(const Rect& r, bool live, int cam_base, const Geo& g,
-                                           unsigned depth, unsigned id, int big_thresh, F&& f) {
-    const Rect s = live ? super_rect(r, g.ss) : Rect{0, 0, 0, 0};
-    const int sw = s.x1 - s.x0, cnt = sw * (s.y1 - s.y0);
-    auto mask_of = [&](int x0, int x1, int y0, int y1, int sx, int sy) -> unsigned {
-        if (!g.ss) return 1u;
-        unsigned m = 0;
-        const int tx = sx << 1, ty = sy << 1;
-        if (ty >= y0 && ty < y1) { if (tx >= x0 && tx < x1) m |= 1u; if (tx + 1 >= x0 && tx + 1 < x1) m |= 2u; }
-        if (ty + 1 >= y0 && ty + 1 < y1) { if (tx >= x0 && tx < x1) m |= 4u; if (tx + 1 >= x0 && tx + 1 < x1) m |= 8u; }
-        return m;
-    };
-    if (cnt > 0 && cnt <= big_thresh) {
-        for (int sy = s.y0; sy < s.y1; ++sy)
-            for (int sx = s.x0; sx < s.x1; ++sx)
-                f(cam_base + sy * g.stw + sx, mask_of(r.x0, r.x1, r.y0, r.y1, sx, sy), depth, id);
-    }
-    unsigned long long big = __ballot(cnt > big_thresh);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int bx0 = __shfl(s.x0, src, 64), by0 = __shfl(s.y0, src, 64);
-        const int bw = __shfl(sw, src, 64), bcnt = __shfl(cnt, src, 64), bbase = __shfl(cam_base, src, 64);
-        const int rx0 = __shfl(r.x0, src, 64), rx1 = __shfl(r.x1, src, 64);
-        const int ry0 = __shfl(r.y0, src, 64), ry1 = __shfl(r.y1, src, 64);
-        const unsigned bd = (unsigned)__shfl((int)depth, src, 64), bi = (unsigned)__shfl((int)id, src, 64);
-        for (int q = sc_lane(); q < bcnt; q += 64) {
-            const int sy = by0 + q / bw, sx = bx0 + q % bw;
-            f(bbase + sy * g.stw + sx, mask_of(rx0, rx1, ry0, ry1, sx, sy), bd, bi);
-        }
-    }
-}
+// ---- pass 2: records ---------------------------------------------------------------------------------
+// One 8-B record (depth bits | tile mask << 28 + id) per (Gaussian, super-tile).  Input: the spatially
+// ordered payload center_scatter wrote (16 B per visible Gaussian, read coalesced: gathering means /
+// radii / depths through a permutation cost 30 us of random 64-B sectors).  The (Gaussian, super-tile)
+// pairs of a wave's 64 Gaussians are FLATTENED: an exclusive scan of the rectangle sizes numbers the
+// pairs 0..T-1, a byte table in LDS maps pair -> owning lane, and lane l handles pairs l, l + 64, ...
+// so every step has 64 busy lanes (the average rectangle has ~9 super-tiles, the largest of a wave up
+// to BIN_BIG).  Rectangles above BIN_BIG are walked by the whole wave, 64 super-tiles per step.
+// Slots: per-workgroup LDS histogram, one global atomic per (workgroup, touched bucket), LDS cursors.
+constexpr int FLAT_THREADS = 256;
+constexpr int FLAT_WAVES = FLAT_THREADS / 64;
+struct FlatTab {                 // per wave
+    int rx0[64], rx1[64], ry0[64], ry1[64];        // tile rectangle (for the 2x2 tile mask)
+    int sx0[64], sy0[64], sw[64], inv[64];         // super-tile rectangle origin, width, 65536 / width + 1
+    int base[64], off[64];                         // camera bucket base, first pair number
+    unsigned depth[64], id[64];
+    unsigned char owner[64 * BIN_BIG];             // pair number -> lane
+};
 
-// GPT = Gaussians per thread (fewer -> more, lighter workgroups: the pass is latency-bound)
-template <int SCAT_GPT>
-__global__ __launch_bounds__(SCAT_THREADS) void bin_scatter_kernel(
-    const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-    const float* __restrict__ depths, const int32_t* __restrict__ perm,
-    const int64_t* __restrict__ n_visible, Geo g, float tile_size, int n_sbuckets,
+__global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
+    const uint4* __restrict__ sorted, const int64_t* __restrict__ n_visible, Geo g, int n_sbuckets,
     const int32_t* __restrict__ soffsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int64_t super_capacity, unsigned* __restrict__ cursor,
     uint2* __restrict__ records, int dbg) {
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
-    const int big_thresh = (dbg >> 8) ? (dbg >> 8) : BIN_BIG;      // tuning knob in debug0's upper bits
     const int64_t M = n_visible[0];
-    constexpr int SCAT_GPB = SCAT_THREADS * SCAT_GPT;
-    const int64_t base = (int64_t)blockIdx.x * SCAT_GPB;
-    if (base >= M) return;
+    const int64_t base_j = (int64_t)blockIdx.x * FLAT_THREADS;
+    if (base_j >= M) return;
     unsigned* hist = lds;                  // [n_sbuckets] counts, then running local cursors
     unsigned* gbase = lds + n_sbuckets;    // [n_sbuckets] global start of this workgroup's slice
-    for (int b = threadIdx.x; b < n_sbuckets; b += SCAT_THREADS) hist[b] = 0;
-    __syncthreads();
-    Rect rr[SCAT_GPT];
-    bool live[SCAT_GPT];
-    int cb[SCAT_GPT];
-    unsigned dd[SCAT_GPT], ii[SCAT_GPT];
-#pragma unroll
-    for (int k = 0; k < SCAT_GPT; ++k) {
-        // consecutive lanes take consecutive Gaussians of the spatial order
-        const int64_t j = base + (int64_t)k * SCAT_THREADS + threadIdx.x;
-        rr[k] = {0, 0, 0, 0};
-        live[k] = j < M;
-        cb[k] = 0; dd[k] = 0; ii[k] = 0;
-        if (live[k]) {
-            const int64_t i = perm[j];
-            const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
-            rr[k] = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
-            cb[k] = (int)(i / g.N) * g.ST;
-            dd[k] = __float_as_uint(depths[i]);
-            ii[k] = (unsigned)i;
-        }
-        walk_super(rr[k], live[k], cb[k], g, 0u, 0u, big_thresh,
-                   [&](int b, unsigned, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
+    const int lane = sc_lane(), wave = threadIdx.x >> 6;
+    FlatTab& tab = reinterpret_cast<FlatTab*>(lds + 2 * n_sbuckets)[wave];
+    for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) hist[b] = 0;
+
+    // consecutive lanes take consecutive Gaussians of the spatial order
+    const int64_t j = base_j + threadIdx.x;
+    Rect r = {0, 0, 0, 0}, sr = {0, 0, 0, 0};
+    int cam_base = 0;
+    unsigned depth = 0, id = 0;
+    if (j < M) {
+        const uint4 pay = sorted[j];
+        r.x0 = (int)(pay.x & 0xffffu); r.x1 = (int)(pay.x >> 16);
+        r.y0 = (int)(pay.y & 0xffffu); r.y1 = (int)(pay.y >> 16);
+        depth = pay.z;
+        id = pay.w;
+        cam_base = (int)(id / (unsigned)g.N) * g.ST;
+        if ((r.x1 - r.x0) * (r.y1 - r.y0) > 0) sr = super_rect(r, g.ss);
     }
+    const int sw = sr.x1 - sr.x0, cnt = sw * (sr.y1 - sr.y0);
+    const bool live = cnt > 0;
+    const int c = (live && cnt <= BIN_BIG) ? cnt : 0;
+    const int incl = sc_wave_incl_scan(c);
+    const int off = incl - c;
+    const int T = __builtin_amdgcn_readlane(incl, 63);
+    tab.rx0[lane] = r.x0; tab.rx1[lane] = r.x1; tab.ry0[lane] = r.y0; tab.ry1[lane] = r.y1;
+    tab.sx0[lane] = sr.x0; tab.sy0[lane] = sr.y0; tab.sw[lane] = sw;
+    tab.inv[lane] = sw > 0 ? 65536 / sw + 1 : 0;              // q / sw == (q * inv) >> 16 for q < 1024
+    tab.base[lane] = cam_base; tab.off[lane] = off; tab.depth[lane] = depth; tab.id[lane] = id;
+    for (int q = 0; q < c; ++q) tab.owner[off + q] = (unsigned char)lane;
+    __syncthreads();                       // hist zeroed, tables complete
+
+    // decode pair number p -> bucket (and, for pass 2, everything the record needs)
+    auto bucket_of = [&](int p, int& o, int& sx, int& sy) -> int {
+        o = tab.owner[p];
+        const int q = p - tab.off[o];
+        const int row = (q * tab.inv[o]) >> 16;
+        sy = tab.sy0[o] + row;
+        sx = tab.sx0[o] + (q - row * tab.sw[o]);
+        return tab.base[o] + sy * g.stw + sx;
+    };
+    // large rectangles: the wave walks them together, 64 super-tiles per step
+    auto walk_big = [&](auto&& f) {
+        unsigned long long big = __ballot(cnt > BIN_BIG);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            Rect br;
+            br.x0 = __builtin_amdgcn_readlane(r.x0, src); br.x1 = __builtin_amdgcn_readlane(r.x1, src);
+            br.y0 = __builtin_amdgcn_readlane(r.y0, src); br.y1 = __builtin_amdgcn_readlane(r.y1, src);
+            const int bx0 = __builtin_amdgcn_readlane(sr.x0, src), by0 = __builtin_amdgcn_readlane(sr.y0, src);
+            const int bw = __builtin_amdgcn_readlane(sw, src), bcnt = __builtin_amdgcn_readlane(cnt, src);
+            const int bbase = __builtin_amdgcn_readlane(cam_base, src);
+            const unsigned bd = (unsigned)__builtin_amdgcn_readlane((int)depth, src);
+            const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)id, src);
+            for (int q = lane; q < bcnt; q += 64) {
+                const int sy = by0 + q / bw, sx = bx0 + q % bw;
+                f(bbase + sy * g.stw + sx, br, sx, sy, bd, bi);
+            }
+        }
+    };
+
+    // pass 1: counts
+    for (int p = lane; p < T; p += 64) {
+        int o, sx, sy;
+        atomicAdd(&hist[bucket_of(p, o, sx, sy)], 1u);
+    }
+    walk_big([&](int b, const Rect&, int, int, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     __syncthreads();
-    for (int b = threadIdx.x; b < n_sbuckets; b += SCAT_THREADS) {
-        const unsigned c = hist[b];
-        if (c) gbase[b] = (unsigned)soffsets[b] + ((dbg & 4) ? 0u : atomicAdd(&cursor[b], c));
+    for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) {
+        const unsigned cb = hist[b];
+        if (cb) gbase[b] = (unsigned)soffsets[b] + atomicAdd(&cursor[b], cb);
         hist[b] = 0;
     }
     __syncthreads();
     if (dbg & 2) return;
-#pragma unroll
-    for (int k = 0; k < SCAT_GPT; ++k) {
-        walk_super(rr[k], live[k], cb[k], g, dd[k], ii[k], big_thresh, [&](int b, unsigned mask, unsigned d, unsigned id) {
-            const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
-            if (!(dbg & 1)) records[slot] = make_uint2(d, id | (mask << 28));
-        });
+    // pass 2: slots + records
+    auto tile_mask = [&](int x0, int x1, int y0, int y1, int sx, int sy) -> unsigned {
+        if (!g.ss) return 1u;
+        unsigned m = 0;
+        const int tx = sx << 1, ty = sy << 1;
+        const bool cx0 = tx >= x0 && tx < x1, cx1 = tx + 1 >= x0 && tx + 1 < x1;
+        if (ty >= y0 && ty < y1) { if (cx0) m |= 1u; if (cx1) m |= 2u; }
+        if (ty + 1 >= y0 && ty + 1 < y1) { if (cx0) m |= 4u; if (cx1) m |= 8u; }
+        return m;
+    };
+    for (int p = lane; p < T; p += 64) {
+        int o, sx, sy;
+        const int b = bucket_of(p, o, sx, sy);
+        const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
+        const unsigned mask = tile_mask(tab.rx0[o], tab.rx1[o], tab.ry0[o], tab.ry1[o], sx, sy);
+        if (!(dbg & 1)) records[slot] = make_uint2(tab.depth[o], tab.id[o] | (mask << 28));
     }
+    walk_big([&](int b, const Rect& br, int sx, int sy, unsigned bd, unsigned bi) {
+        const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
+        if (!(dbg & 1)) records[slot] = make_uint2(bd, bi | (tile_mask(br.x0, br.x1, br.y0, br.y1, sx, sy) << 28));
+    });
 }
 
 // ---- pass 3: per-super-tile sort + emit ---------------------------------------------------------------
@@ -396,8 +430,12 @@ constexpr int SS_RPT = SS_MAX_CAP / SS_THREADS;  // records per thread held in r
 // Emits the per-tile lists of one super-tile from its records sorted on (depth, id) in LDS.
 // Stable filter per tile: rank of record i in tile k's list = number of records j < i with mask bit k;
 // computed per (round, wave) with ballots, bases by a tiny scan over the (round, wave) table.
+// `order` (nullable): when given, the sorted sequence is S[order[0]], S[order[1]], ... (the
+// interpolation sort keeps 2-byte ranks instead of a second copy of the keys: 14 instead of 20 B of LDS
+// per record, i.e. three resident workgroups per CU instead of two)
 template <int THREADS>
-__device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict__ S, int n, int sb, const Geo& g,
+__device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict__ S,
+                                           const unsigned short* __restrict__ order, int n, int sb, const Geo& g,
                                            const int32_t* __restrict__ offsets, int n_tiles_total,
                                            int64_t n_isects, int tile_bits, unsigned long long* table,
                                            int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
@@ -411,7 +449,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     // pass A: per (round, wave) packed counts (16 bits per tile; a tile list has <= 9216 entries)
     for (int r = 0; r < rounds; ++r) {
         const int i = r * THREADS + t;
-        const unsigned m = (i < n) ? (unsigned)((S[i] >> 28) & 0xfu) : 0u;
+        const unsigned m = (i < n) ? (unsigned)((S[order ? order[i] : i] >> 28) & 0xfu) : 0u;
         unsigned long long packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -451,7 +489,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     if (dbg & 1) return;
     for (int r = 0; r < rounds; ++r) {
         const int i = r * THREADS + t;
-        const unsigned long long key = (i < n) ? S[i] : 0ull;
+        const unsigned long long key = (i < n) ? S[order ? order[i] : i] : 0ull;
         const unsigned m = (i < n) ? (unsigned)((key >> 28) & 0xfu) : 0u;
         const unsigned long long base = table[r * WAVES + wave];
 #pragma unroll
@@ -480,10 +518,10 @@ __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
     int64_t rec_capacity, int tile_bits, int cap, int per_thread, unsigned char* __restrict__ needs_radix,
     int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
-    // [B: cap u64][S: cap u64][boff: SS_THREADS*per_thread + 1 u32][table]
+    // [B: cap u64][order: cap u16][boff: SS_THREADS*per_thread + 1 u32][table]
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
-    unsigned long long* S = B + cap;
-    unsigned* boff = reinterpret_cast<unsigned*>(S + cap);
+    unsigned short* order = reinterpret_cast<unsigned short*>(B + cap);      // cap is a multiple of 256
+    unsigned* boff = reinterpret_cast<unsigned*>(order + cap);
     const int nbk = SS_THREADS * per_thread;
     unsigned long long* table = reinterpret_cast<unsigned long long*>(boff + ((nbk + 2) & ~1));
     __shared__ unsigned red_lo[SS_WAVES], red_hi[SS_WAVES], red_sum[SS_WAVES], red_occ[SS_WAVES];
@@ -572,7 +610,7 @@ __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
     }
     __syncthreads();
     if (dbg & 2) return;
-    // rank inside the sub-bucket by (depth bits, flat id) -> sorted array S
+    // rank inside the sub-bucket by (depth bits, flat id) -> order[rank] = position in B
     for (int p = t; p < n; p += SS_THREADS) {
         const unsigned long long key = B[p];
         const unsigned long long kk = key & KEY_MASK;
@@ -580,10 +618,10 @@ __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
         const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
         unsigned r = beg;
         for (unsigned q = beg; q < end; ++q) r += ((B[q] & KEY_MASK) < kk) ? 1u : 0u;
-        S[r] = key;
+        order[r] = (unsigned short)p;
     }
     __syncthreads();
-    emit_tiles<SS_THREADS>(S, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, dbg);
+    emit_tiles<SS_THREADS>(B, order, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, dbg);
 }
 
 // ---- radix fallback for flagged super-tiles --------------------------------------------------------------
@@ -697,7 +735,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
             unsigned long long* tmp = src; src = dst; dst = tmp;
             done += bits;
         }
-        emit_tiles<TS_THREADS>(src, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, 0);
+        emit_tiles<TS_THREADS>(src, nullptr, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, 0);
     }
 }
 
@@ -705,7 +743,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 
 // ---- host side --------------------------------------------------------------------------------
 // count-phase workspace (handed to BOTH calls):
-//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | soffsets | cstart | smeta[2] | cmeta[2] | perm[CN]
+//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | soffsets | cstart | smeta[2] | cmeta[2] | sorted uint4[CN]
 //   (everything before soffsets is zeroed by the ONE memset of a frame; rcursor / rflags are the
 //    scatter's bucket cursors and the "needs the radix fallback" flags of the sort phase, kept here so
 //    that the sort phase needs no memset of its own: a second memset cost 5 us + a 6 us bubble)
@@ -714,7 +752,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
-    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, soffsets, cstart, smeta, cmeta, perm, total;
+    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, soffsets, cstart, smeta, cmeta, sorted, total;
 };
 
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
@@ -740,7 +778,7 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.cstart = take((size_t)L.nsb * 4);
     L.smeta = take(16);
     L.cmeta = take(16);
-    L.perm = take((size_t)(CN > 0 ? CN : 0) * 4);
+    L.sorted = take((size_t)(CN > 0 ? CN : 0) * 16);
     L.total = o;
     return L;
 }
@@ -758,7 +796,8 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
     return sc_align_up((size_t)n_isects * 8, 256) + 256;
 }
 
-extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, int C, int N, int tile_size,
+extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
+                                  int tile_size,
                                   int tile_width, int tile_height, int32_t* tiles_per_gauss,
                                   int32_t* isect_offsets, int64_t* meta_dev, int64_t* meta_mirror,
                                   int64_t seq, void* count_workspace, size_t ws_bytes, sc_stream_t stream) {
@@ -777,7 +816,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
         }
         return SC_OK;
     }
-    if (!means2d || !radii || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
+    if (!means2d || !radii || !depths || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
     const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
     if (ws_bytes < L.total) return SC_EWORKSPACE;
     if (count_lds_bytes(L) > 150 * 1024 || (size_t)L.nt_cells * 4 > 150 * 1024) return SC_EUNSUPPORTED;
@@ -789,7 +828,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     int32_t* soffsets = (int32_t*)(ws + L.soffsets);
     int32_t* cstart = (int32_t*)(ws + L.cstart);
     int64_t* cmeta = (int64_t*)(ws + L.cmeta);
-    int32_t* perm = (int32_t*)(ws + L.perm);
+    uint4* sorted = (uint4*)(ws + L.sorted);
     SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
     static bool attr_set = false;
     if (!attr_set) {
@@ -812,7 +851,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, in
     SC_LAUNCH_CHECK();
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)L.nsb * 8, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
-                       (const int32_t*)cstart, ccursor, perm, (const int64_t*)meta_dev, meta_mirror, seq);
+                       depths, (const int32_t*)cstart, ccursor, sorted, (const int64_t*)meta_dev, meta_mirror, seq);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
@@ -843,23 +882,15 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     unsigned char* cws = (unsigned char*)count_workspace;
     const int32_t* soffsets = (const int32_t*)(cws + L.soffsets);
     const int64_t* cmeta = (const int64_t*)(cws + L.cmeta);
-    const int32_t* perm = (const int32_t*)(cws + L.perm);
+    const uint4* sorted = (const uint4*)(cws + L.sorted);
     // zero since sc_isect_bin_count; consumed by the one launch whose capacities pass the device-side
     // check (kernels of a launch with too small capacities return before touching them)
     unsigned* cursor = (unsigned*)(cws + L.rcursor);
     unsigned char* needs_radix = cws + L.rflags;
     uint2* records = (uint2*)workspace;
-#define SC_LAUNCH_SCATTER(GPT)                                                                               \
-    hipLaunchKernelGGL(bin_scatter_kernel<GPT>, dim3((unsigned)((CN + SCAT_THREADS * GPT - 1) / (SCAT_THREADS * GPT))), \
-                       dim3(SCAT_THREADS), (size_t)L.nsb * 8, s, means2d, radii, depths, perm, cmeta, L.g,          \
-                       (float)tile_size, L.nsb, soffsets, meta_dev, capacity, rec_capacity, (int64_t)cap, cursor,   \
-                       records, g_sc_debug[0])
-    switch (g_sc_debug[3]) {            // tuning knob: Gaussians per thread (default 2)
-        case 1: SC_LAUNCH_SCATTER(1); break;
-        case 4: SC_LAUNCH_SCATTER(4); break;
-        default: SC_LAUNCH_SCATTER(2); break;
-    }
-#undef SC_LAUNCH_SCATTER
+    hipLaunchKernelGGL(bin_scatter_flat_kernel, dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
+                       dim3(FLAT_THREADS), (size_t)L.nsb * 8 + FLAT_WAVES * sizeof(FlatTab), s, sorted, cmeta, L.g, L.nsb,
+                       soffsets, meta_dev, capacity, rec_capacity, (int64_t)cap, cursor, records, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
     const int id_bits = sc_bits_for(CN > 1 ? CN - 1 : 1);
@@ -869,7 +900,7 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     per_thread |= 1;
     const int nbk = SS_THREADS * per_thread;
     const size_t table_bytes = (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64;
-    const size_t lds_sort = (size_t)cap * 16 + (size_t)((nbk + 2) & ~1) * 4 + table_bytes;
+    const size_t lds_sort = (size_t)cap * 10 + (size_t)((nbk + 2) & ~1) * 4 + table_bytes;
     const size_t table_radix = (size_t)((cap + TS_THREADS - 1) / TS_THREADS + 1) * TS_WAVES * 8 + 64;
     const size_t lds_radix = (size_t)cap * 16 + table_radix;
     if (lds_sort > 156 * 1024) return SC_EUNSUPPORTED;

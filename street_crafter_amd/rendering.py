@@ -229,7 +229,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     meta_host, meta_np = slot[0], slot[1]
     slot[2] += 1
     seq = slot[2]
-    rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
+    rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
                                 meta_host.data_ptr(), seq, _p(ws0), ws0.numel(), st)
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
