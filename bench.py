@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
     ap.add_argument("--raster-variant", type=int, default=None)
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="skip the secondary fused rasterization() measurement (keeps profiles of the headline clean)")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
     return ap.parse_args()
@@ -181,7 +183,7 @@ def main():
     # whose forward is fused (projection + SH + glue in one kernel, depth normalisation in the raster
     # epilogue).  `value` above stays the reference caller's own operator sequence.
     fused_line = None
-    if world == 1:
+    if world == 1 and not args.no_fused:
         from gsplat.rendering import rasterization
         op1 = scene.opacities[:, 0].contiguous()
 

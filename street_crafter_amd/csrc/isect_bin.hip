@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 // so every step has 64 busy lanes (the average rectangle has ~9 super-tiles, the largest of a wave up
 // to BIN_BIG).  Rectangles above BIN_BIG are walked by the whole wave, 64 super-tiles per step.
 // Slots: per-workgroup LDS histogram, one global atomic per (workgroup, touched bucket), LDS cursors.
-constexpr int FLAT_THREADS = 256;
+constexpr int FLAT_THREADS = 512;                // A/B on S-1M: 256 -> 52 us, 512 -> 47, 1024 -> 51
 constexpr int FLAT_WAVES = FLAT_THREADS / 64;
 struct FlatTab {                 // per wave
     int rx0[64], rx1[64], ry0[64], ry1[64];        // tile rectangle (for the 2x2 tile mask)
