@@ -400,11 +400,15 @@ class _Rasterize(torch.autograd.Function):
         dev = means2d.device
         v_render_colors = v_render_colors.contiguous()
         v_render_alphas = v_render_alphas.contiguous()
-        v_means2d = torch.zeros_like(means2d)
-        v_conics = torch.zeros_like(conics)
-        v_colors = torch.zeros_like(colors)
-        v_opacities = torch.zeros_like(opacities)
-        v_abs = torch.zeros_like(means2d) if absgrad else None
+        # the kernel accumulates with float atomics: ONE zero-fill for all five gradient buffers
+        sizes = (2 * C * N, 3 * C * N, D * C * N, C * N, 2 * C * N if absgrad else 0)
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        parts = torch.split(flat, sizes)
+        v_means2d = parts[0].view(C, N, 2)
+        v_conics = parts[1].view(C, N, 3)
+        v_colors = parts[2].view(C, N, D)
+        v_opacities = parts[3].view(C, N)
+        v_abs = parts[4].view(C, N, 2) if absgrad else None
         _lib.check(lib.sc_rasterize_bwd(_p(means2d), _p(conics), _p(colors), _p(opacities),
                                         _p(backgrounds) if has_bg else None, _p(masks) if has_mask else None,
                                         C, N, D, width, height, tile_size, tw, th, _p(isect_offsets),
