@@ -271,27 +271,31 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
     if (range_end <= range_start) return;
 
-    float pxf[4], T[4], T_final[4], v_ra[4], bgdot[4];
-    float buf[4][CDIM], v_rc[4][CDIM];
+    // per-pixel state in pairs (pixels 2p, 2p+1): x centre, running transmittance, T_final (v_alpha - bg.v_c),
+    // colour sums behind the current splat, upstream colour gradients
+    sc_f2 pxp[2], T2[2], wfin[2], buf2[2][CDIM], vrc[2][CDIM];
     int bin_final[4];
-    bool inside[4];
+    bool ins[4];
     int tile_last = -1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        pxf[k] = (float)(px0_i + k) + 0.5f;
-        inside[k] = (px0_i + k < width) && (py_i < height);
+        const int p = k >> 1, h = k & 1;
+        ins[k] = (px0_i + k < width) && (py_i < height);
         const int64_t pix = ((int64_t)cam * height + py_i) * width + px0_i + k;
-        T_final[k] = inside[k] ? 1.0f - render_alphas[pix] : 1.0f;
-        T[k] = T_final[k];
-        v_ra[k] = inside[k] ? v_render_alphas[pix] : 0.f;
-        bin_final[k] = inside[k] ? last_ids[pix] : -1;
-        bgdot[k] = 0.f;
+        const float T_fin = ins[k] ? 1.0f - render_alphas[pix] : 1.0f;
+        const float v_ra = ins[k] ? v_render_alphas[pix] : 0.f;
+        bin_final[k] = ins[k] ? last_ids[pix] : -1;
+        float bgdot = 0.f;
+        pxp[p][h] = (float)(px0_i + k) + 0.5f;
+        T2[p][h] = T_fin;
 #pragma unroll
         for (int d = 0; d < CDIM; ++d) {
-            buf[k][d] = 0.f;
-            v_rc[k][d] = inside[k] ? v_render_colors[pix * CDIM + d] : 0.f;
-            if (backgrounds) bgdot[k] += backgrounds[cam * CDIM + d] * v_rc[k][d];
+            const float g = ins[k] ? v_render_colors[pix * CDIM + d] : 0.f;
+            buf2[p][d][h] = 0.f;
+            vrc[p][d][h] = g;
+            if (backgrounds) bgdot += backgrounds[cam * CDIM + d] * g;
         }
+        wfin[p][h] = T_fin * (v_ra - bgdot);
         tile_last = max(tile_last, bin_final[k]);
     }
 #pragma unroll
@@ -363,47 +367,72 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
             const int sidx = __float_as_int(bc.z);
             const float dy = a.y - py;
             const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);
-            const float inv_op = __builtin_amdgcn_exp2f(-a.z);              // 1 / opacity
+            // Two pixels per VALU op (v_pk_*).  Per-pixel work is kept to what cannot be factored out:
+            // with v_sigma = dL/dsigma2-ish of a pixel and dx its offset, the conic, mean and opacity
+            // gradients of the splat only need  Sv = sum v_sigma,  Sx = sum v_sigma dx,  Sxx = sum
+            // v_sigma dx^2  (dy, A2, B2, C2, 1/op are the same for the lane's four pixels), so they are
+            // assembled once per splat below; only |grad mean| (absgrad) needs the per-pixel values.
+            sc_f2 Sc[CDIM], Sv = {0.f, 0.f}, Sx = {0.f, 0.f}, Sxx = {0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < CDIM; ++d) Sc[d] = sc_f2{0.f, 0.f};
+            float s_xa = 0.f, s_ya = 0.f;
+            bool any_valid = false;
+            const float bdy_ln2 = LN2 * bc.x * dy, a2_ln2 = LN2 * 2.0f * a.w;       // d sigma / d mean_x pieces
+            const float b2_ln2 = LN2 * bc.x, c2dy_ln2 = LN2 * 2.0f * bc.y * dy;     // d sigma / d mean_y pieces
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const sc_f2 dx = sc_f2{a.x, a.x} - pxp[p];
+                const sc_f2 sg = __builtin_elementwise_fma(
+                    __builtin_elementwise_fma(sc_f2{a.w, a.w}, dx, sc_f2{bdy, bdy}), dx, sc_f2{qdy, qdy});
+                const sc_f2 e = sc_f2{a.z, a.z} - sg;
+                const sc_f2 araw = sc_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};   // op exp(-sigma)
+                const sc_f2 al = sc_f2{fminf(SC_ALPHA_MAX, araw.x), fminf(SC_ALPHA_MAX, araw.y)};
+                const bool v0 = ins[2 * p] && (sidx <= bin_final[2 * p]) && sc_valid(sg.x, al.x);
+                const bool v1 = ins[2 * p + 1] && (sidx <= bin_final[2 * p + 1]) && sc_valid(sg.y, al.y);
+                any_valid = any_valid || v0 || v1;
+                const sc_f2 om = sc_f2{1.0f, 1.0f} - al;                              // >= 1e-3
+                const sc_f2 ra = sc_f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
+                const sc_f2 Tn = T2[p] * ra;                                          // transmittance in front
+                const sc_f2 at = al * Tn;
+                const sc_f2 fac = sc_f2{v0 ? at.x : 0.f, v1 ? at.y : 0.f};
+                sc_f2 va = wfin[p] * ra;                                              // T_final (v_alpha - bg.v_c) / (1 - alpha)
+#pragma unroll
+                for (int d = 0; d < CDIM; ++d) {
+                    Sc[d] = __builtin_elementwise_fma(fac, vrc[p][d], Sc[d]);
+                    const sc_f2 front = sc_f2{cl[d], cl[d]} * Tn;
+                    va = __builtin_elementwise_fma(__builtin_elementwise_fma(-buf2[p][d], ra, front), vrc[p][d], va);
+                    buf2[p][d] = __builtin_elementwise_fma(sc_f2{cl[d], cl[d]}, fac, buf2[p][d]);
+                }
+                // sigma = sigma2 ln2;  d alpha / d sigma = -alpha_raw (only while alpha is not clamped)
+                const bool l0 = v0 && araw.x <= SC_ALPHA_MAX, l1 = v1 && araw.y <= SC_ALPHA_MAX;
+                const sc_f2 vsr = araw * va;
+                const sc_f2 vs = sc_f2{l0 ? -vsr.x : 0.f, l1 ? -vsr.y : 0.f};
+                const sc_f2 vd = vs * dx;
+                Sv += vs;
+                Sx += vd;
+                Sxx = __builtin_elementwise_fma(vd, dx, Sxx);
+                if (v_means2d_abs) {                                                  // uniform
+                    const sc_f2 gx = __builtin_elementwise_fma(sc_f2{a2_ln2, a2_ln2}, vd, sc_f2{bdy_ln2, bdy_ln2} * vs);
+                    const sc_f2 gy = __builtin_elementwise_fma(sc_f2{b2_ln2, b2_ln2}, vd, sc_f2{c2dy_ln2, c2dy_ln2} * vs);
+                    s_xa += fabsf(gx.x) + fabsf(gx.y);
+                    s_ya += fabsf(gy.x) + fabsf(gy.y);
+                }
+                T2[p] = sc_f2{v0 ? Tn.x : T2[p].x, v1 ? Tn.y : T2[p].y};
+            }
+            if (!__any(any_valid)) continue;
+            const float sv = Sv.x + Sv.y, sx = Sx.x + Sx.y, sxx = Sxx.x + Sxx.y;
             float s[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[i] = 0.f;
-            bool any_valid = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dx = a.x - pxf[k];
-                const float sigma2 = sc_sigma2(a.w, bdy, qdy, dx);
-                const float e = __fsub_rn(a.z, sigma2);
-                const float alpha_raw = __builtin_amdgcn_exp2f(e);           // op * exp(-sigma)
-                const float alpha = fminf(SC_ALPHA_MAX, alpha_raw);          // == sc_alpha2(a.z, sigma2)
-                const bool valid = inside[k] && (sidx <= bin_final[k]) && sc_valid(sigma2, alpha);
-                any_valid = any_valid || valid;
-                const float ra = __builtin_amdgcn_rcpf(1.0f - alpha);        // 1 - alpha >= 1e-3
-                const float Tn = T[k] * ra;                                   // transmittance in front of this splat
-                const float fac = valid ? alpha * Tn : 0.f;
-                float v_alpha = 0.f;
-#pragma unroll
-                for (int d = 0; d < CDIM; ++d) {
-                    s[d] += fac * v_rc[k][d];
-                    v_alpha += (cl[d] * Tn - buf[k][d] * ra) * v_rc[k][d];
-                    buf[k][d] += cl[d] * fac;
-                }
-                v_alpha += T_final[k] * ra * (v_ra[k] - bgdot[k]);
-                // sigma = sigma2 ln2;  d alpha / d sigma = -alpha_raw (only while alpha is not clamped)
-                const bool live = valid && alpha_raw <= SC_ALPHA_MAX;
-                const float v_sigma = live ? -alpha_raw * v_alpha : 0.f;
-                s[4] += 0.5f * v_sigma * dx * dx;
-                s[5] += v_sigma * dx * dy;
-                s[6] += 0.5f * v_sigma * dy * dy;
-                // d sigma / d mean = (a dx + b dy, b dx + c dy) = ln2 (2 A2 dx + B2 dy, B2 dx + 2 C2 dy)
-                const float gx = v_sigma * LN2 * (2.0f * a.w * dx + bc.x * dy);
-                const float gy = v_sigma * LN2 * (bc.x * dx + 2.0f * bc.y * dy);
-                s[7] += gx; s[8] += gy;
-                s[9] += fabsf(gx); s[10] += fabsf(gy);
-                // d alpha / d op = exp(-sigma) = alpha_raw / op
-                s[11] += live ? alpha_raw * inv_op * v_alpha : 0.f;
-                T[k] = valid ? Tn : T[k];
-            }
-            if (!__any(any_valid)) continue;
+            for (int d = 0; d < CDIM; ++d) s[d] = Sc[d].x + Sc[d].y;
+            s[4] = 0.5f * sxx;                       // d sigma / d conic = (dx^2 / 2, dx dy, dy^2 / 2)
+            s[5] = dy * sx;
+            s[6] = 0.5f * dy * dy * sv;
+            s[7] = a2_ln2 * sx + bdy_ln2 * sv;       // d sigma / d mean = ln2 (2 A2 dx + B2 dy, B2 dx + 2 C2 dy)
+            s[8] = b2_ln2 * sx + c2dy_ln2 * sv;
+            s[9] = s_xa; s[10] = s_ya;
+            s[11] = -__builtin_amdgcn_exp2f(-a.z) * sv;   // d alpha / d op = alpha_raw / op, i.e. -v_sigma / op
             const float total = wave_transpose_sum16(s, lane);
             if (out_base) atomicAdd(out_base + (int64_t)__float_as_int(bc.w) * out_stride, total);
         }
