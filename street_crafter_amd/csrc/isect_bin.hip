@@ -915,7 +915,7 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
                        L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, cap, per_thread,
                        needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
     SC_LAUNCH_CHECK();
-    const int rgrid = L.nsb < 512 ? L.nsb : 512;
+    const int rgrid = L.nsb < 512 ? L.nsb : 512;      // persistent; A/B when no super-tile is flagged: 128 -> 8.5 us, 512 -> 4.8 us
     hipLaunchKernelGGL(super_radix_kernel, dim3(rgrid), dim3(TS_THREADS), lds_radix, s, (const uint2*)records, soffsets,
                        L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, id_bits, cap,
                        (const unsigned char*)needs_radix, isect_ids, flatten_ids);

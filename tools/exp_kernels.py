@@ -23,11 +23,8 @@ cam = make_camera().to(dev)
 
 CONFIGS = [
     ("baseline", {}),
-    ("scatter: 1 gaussian/thread", {"debug3": 1}),
-    ("scatter: 4 gaussians/thread", {"debug3": 4}),
     ("scatter: no record store", {"debug0": 1}),
     ("scatter: no pass 2", {"debug0": 2}),
-    ("scatter: no reservation atomics", {"debug0": 4}),
     ("raster: no blend loop", {"debug1": 1}),
     ("bucket sort: no final stores", {"debug2": 1}),
     ("bucket sort: no rank loop/stores", {"debug2": 2}),
@@ -37,7 +34,6 @@ CONFIGS = [
     ("raster variant 2", {"raster_fwd": 2}),
     ("raster variant 3", {"raster_fwd": 3}),
     ("raster variant 4", {"raster_fwd": 4}),
-    ("raster variant 4, no blend", {"raster_fwd": 4, "debug1": 1}),
 ]
 
 
