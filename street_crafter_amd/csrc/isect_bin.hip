@@ -498,7 +498,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
             if (((m >> k) & 1u) && tok[k]) {
                 const int pos = tbase[k] + (int)((base >> (16 * k)) & 0xffffu) + __popcll(bal & sc_lanemask_lt());
                 if (pos < tend[k]) {
-                    if (isect_ids) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
+                    if (isect_ids && !(dbg & 16)) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
                     flatten_ids[pos] = (int32_t)((unsigned)key & ID_MASK);
                 }
             }

@@ -180,7 +180,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
                                tiles_per_gauss, total_dev, st)
         if res is not None:
-            return res
+            return res[:3]
     wsb = lib.sc_isect_workspace_bytes(C * N)
     ws = _ws(wsb, dev)
     _lib.check(lib.sc_isect_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
@@ -215,7 +215,10 @@ _PINNED_META = {}      # device index -> [pinned int64[8] the device publishes m
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                     tiles_per_gauss, total_dev, st):
+                     tiles_per_gauss, total_dev, st, want_ids=True):
+    """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
+    the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
+    rasterization() forward never reads it: 16 us of stores per S-1M frame)."""
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
     meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
@@ -252,7 +255,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
     def launch(capacity, rec_capacity, super_capacity):
-        ids = torch.empty(capacity, dtype=torch.int64, device=dev)
+        ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
         fids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, rec_capacity), dev)
         r = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
@@ -278,11 +281,14 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     # next call: 12.5 % head-room over what this frame needed
     _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, n_records + n_records // 8 + 4096,
                             min(7168, max_super + max_super // 8 + 64))
-    isect_ids, flatten_ids = ids[:n_isects], fids[:n_isects]
-    # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
-    # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
-    isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
-    return tiles_per_gauss, isect_ids, flatten_ids
+    flatten_ids = fids[:n_isects]
+    isect_ids = None
+    if want_ids:
+        isect_ids = ids[:n_isects]
+        # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
+        # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
+        isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
+    return tiles_per_gauss, isect_ids, flatten_ids, offsets
 
 
 # ------------------------------------------------------------------------------------------
@@ -509,6 +515,21 @@ def _fused_forward_ok(tensors, sh_degree, render_mode, tile_size, colors) -> boo
     return True
 
 
+class _FusedMeta(dict):
+    """gsplat's meta dict.  The fused forward does not materialise `isect_ids` (8 B x I of keys nothing on
+    this path reads); `meta["isect_ids"]` builds them on first access from the tensors already here."""
+
+    def __missing__(self, key):
+        if key != "isect_ids":
+            raise KeyError(key)
+        with torch.no_grad():
+            _, ids, _ = isect_tiles(self["means2d"], self["radii"], self["depths"], self["tile_size"],
+                                    self["tile_width"], self["tile_height"], packed=False,
+                                    n_cameras=self["n_cameras"])
+        self[key] = ids
+        return ids
+
+
 @torch.no_grad()
 def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane,
                          far_plane, radius_clip, eps2d, sh_degree, tile_size, backgrounds, render_mode,
@@ -538,9 +559,17 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                                         _p(opac), _p(cols), st), "sc_projection_sh_fwd")
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
-    tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width,
-                                                          tile_height, packed=False, n_cameras=C)
-    isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
+    res = None
+    if _ISECT_MODE["mode"] == "bin":
+        tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
+        res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
+                               tiles_per_gauss, None, st, want_ids=False)
+    if res is not None:
+        tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = res
+    else:
+        tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(means2d, radii, depths, tile_size, tile_width,
+                                                              tile_height, packed=False, n_cameras=C)
+        isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
     if backgrounds is not None:
         backgrounds = torch.cat([_req(backgrounds, "backgrounds"),
                                  torch.zeros(C, 1, device=dev)], dim=-1).contiguous()
@@ -560,11 +589,13 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
             _lib.check(rc, "sc_rasterize_fwd_ed")
     else:
         _lib.check(lib.sc_rasterize_fwd(*args, None, _p(ws), ws.numel(), st), "sc_rasterize_fwd")
-    meta = {"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
-            "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
-            "isect_ids": isect_ids, "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
-            "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "colors": cols,
-            "fused": True}
+    meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+                       "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
+                       "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
+                       "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "colors": cols,
+                       "fused": True})
+    if isect_ids is not None:
+        meta["isect_ids"] = isect_ids
     return render_colors, render_alphas, meta
 
 
