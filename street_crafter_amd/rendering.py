@@ -55,6 +55,32 @@ def _req(t: Tensor, name: str, dtype=torch.float32):
     return t.contiguous()
 
 
+class _NoGradCtx:
+    """Stands in for the autograd context when no gradient can be required: the forward bodies run
+    directly, without torch.autograd.Function.apply's bookkeeping (~10 us of host time per operator,
+    which is what bounds small scenes)."""
+    needs_input_grad = (False,) * 16
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def __setattr__(self, name, value):      # ctx.meta = ... etc.: nothing is kept
+        pass
+
+
+_NO_GRAD_CTX = _NoGradCtx()
+
+
+def _call(fn, *args):
+    """fn.apply(*args), or fn.forward on a dummy context when autograd has nothing to record."""
+    if torch.is_grad_enabled() and any(isinstance(a, Tensor) and a.requires_grad for a in args):
+        return fn.apply(*args)
+    return fn.forward(_NO_GRAD_CTX, *args)
+
+
 def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
@@ -144,7 +170,7 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
     assert scales.shape == (N, 3), scales.shape
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
-    out = _Projection.apply(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+    out = _call(_Projection, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                             far_plane, radius_clip, calc_compensations)
     if calc_compensations:
         return out
@@ -358,7 +384,7 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
             masks = masks.to(torch.uint8).contiguous()
         else:
             masks = masks.contiguous()
-    return _SphericalHarmonics.apply(int(degrees_to_use), dirs, coeffs, masks)
+    return _call(_SphericalHarmonics, int(degrees_to_use), dirs, coeffs, masks)
 
 
 # ------------------------------------------------------------------------------------------
@@ -476,7 +502,7 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
             raise RuntimeError("masks must live on a HIP device")
         masks = masks.to(torch.uint8).contiguous()
 
-    return _Rasterize.apply(means2d_c, conics, colors, opacities, backgrounds, masks, int(image_width),
+    return _call(_Rasterize, means2d_c, conics, colors, opacities, backgrounds, masks, int(image_width),
                             int(image_height), int(tile_size), isect_offsets, flatten_ids, bool(absgrad),
                             _AbsgradTarget(caller_means2d))
 
