@@ -170,19 +170,16 @@ __device__ __forceinline__ void line_prefix8(int* base, int n, int stride, int s
         for (int i = b; i < e; ++i) base[i * stride] += off;
 }
 
-// One launch, three independent single-workgroup jobs (blockIdx.x):
+// Single-workgroup scan jobs (run as extra blocks of the centre-scatter launch):
 //   0: tile difference grid  -> per-tile counts -> exclusive scan = isect_offsets; meta[0..1]
 //   1: super-tile difference grid -> record offsets;                               meta[2..3]
-//   2: centre histogram -> start of each centre bucket in the spatial order;       cmeta[0..1]
+// (is_grid == 0: plain exclusive scan of a count array)
 // A difference grid [C][gh+1][gw+1] becomes counts by a 2-D prefix sum (x then y).
 struct ScanJob { const int* src; int C, gw, gh; int32_t* out; int64_t* meta; int is_grid; };
 struct ScanJobs { ScanJob j[3]; };
 
-__global__ __launch_bounds__(1024) void bin_scan_kernel(ScanJobs jobs) {
-    extern __shared__ int grid[];
-    __shared__ long long wave_tot[16];
-    __shared__ unsigned wave_max[16];
-    const ScanJob job = jobs.j[blockIdx.x];
+__device__ __forceinline__ void run_scan_job(const ScanJob& job, int* grid, long long* wave_tot,
+                                             unsigned* wave_max) {
     const int t = threadIdx.x;
     const int gw = job.gw, gh = job.gh, C = job.C;
     const int n = C * gh * gw;
@@ -234,6 +231,7 @@ __global__ __launch_bounds__(1024) void bin_scan_kernel(ScanJobs jobs) {
     if (t == 0) { job.meta[0] = tot; job.meta[1] = (long long)m; }
 }
 
+
 // ---- spatial order: counting sort of the visible Gaussians by centre super-tile --------------------
 // The host needs meta (the output sizes) once per frame.  Instead of a D2H copy + event on the stream
 // (a copy kernel plus a ~6 us barrier bubble between the count and the scatter kernels), one lane
@@ -247,15 +245,44 @@ __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
 }
 
+// The launch also carries the two grid scans (blocks n_center, n_center + 1): they depend on the count
+// pass only, like this kernel, so they run beside it instead of in front of it (the separate scan
+// launch sat 13 us on the critical path).  Every centre workgroup builds the bucket starts itself, by a
+// block scan of the 2400-entry centre histogram.  The scan block that finishes second publishes meta.
 __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
-    const float* __restrict__ depths, const int32_t* __restrict__ cstart, unsigned* __restrict__ ccursor,
-    uint4* __restrict__ sorted, const int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
+    const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
+    uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, int n_center, ScanJobs jobs,
+    unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
     extern __shared__ unsigned lds[];
-    unsigned* hist = lds;                // [n_sbuckets]
-    unsigned* gbase = lds + n_sbuckets;  // [n_sbuckets]
-    if (meta_mirror && blockIdx.x == 0 && threadIdx.x == 0) publish_meta(meta_dev, meta_mirror, seq);
+    __shared__ long long wave_tot[16];
+    __shared__ unsigned wave_max[16];
+    if ((int)blockIdx.x >= n_center) {
+        run_scan_job(jobs.j[blockIdx.x - n_center], reinterpret_cast<int*>(lds), wave_tot, wave_max);
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(scans_done, 1u) == 1u && meta_mirror) {       // both halves of meta are in place
+                __threadfence();
+                publish_meta(meta_dev, meta_mirror, seq);
+            }
+        }
+        return;
+    }
+    unsigned* hist = lds;                    // [n_sbuckets]
+    unsigned* gbase = lds + n_sbuckets;      // [n_sbuckets]
+    unsigned* cst = lds + 2 * n_sbuckets;    // [n_sbuckets] first slot of each centre bucket in the spatial order
+    {
+        const int per = (n_sbuckets + BIN_THREADS - 1) / BIN_THREADS;
+        const int beg = min((int)threadIdx.x * per, n_sbuckets), end = min(beg + per, n_sbuckets);
+        long long sum = 0;
+        for (int i = beg; i < end; ++i) sum += chist[i];
+        long long tot;
+        unsigned mx;
+        long long run = block_scan_1024(sum, 0u, &tot, &mx, wave_tot, wave_max);
+        for (int i = beg; i < end; ++i) { cst[i] = (unsigned)run; run += chist[i]; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { cmeta[0] = tot; cmeta[1] = 0; }   // number of visible Gaussians
+    }
     for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) hist[b] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
@@ -280,15 +307,13 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     __syncthreads();
     for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) {
         const unsigned c = hist[b];
-        if (c) gbase[b] = (unsigned)cstart[b] + atomicAdd(&ccursor[b], c);
+        if (c) gbase[b] = cst[b] + atomicAdd(&ccursor[b], c);
         hist[b] = 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BIN_GPT; ++k) {
-        const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+    for (int k = 0; k < BIN_GPT; ++k)
         if (cb[k] >= 0) sorted[gbase[cb[k]] + atomicAdd(&hist[cb[k]], 1u)] = pay[k];
-    }
 }
 
 // ---- pass 2: records ---------------------------------------------------------------------------------
@@ -743,7 +768,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 
 // ---- host side --------------------------------------------------------------------------------
 // count-phase workspace (handed to BOTH calls):
-//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | soffsets | cstart | smeta[2] | cmeta[2] | sorted uint4[CN]
+//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | scans_done | soffsets | cstart | smeta[2] | cmeta[2] | sorted uint4[CN]
 //   (everything before soffsets is zeroed by the ONE memset of a frame; rcursor / rflags are the
 //    scatter's bucket cursors and the "needs the radix fallback" flags of the sort phase, kept here so
 //    that the sort phase needs no memset of its own: a second memset cost 5 us + a 6 us bubble)
@@ -752,7 +777,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
-    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, soffsets, cstart, smeta, cmeta, sorted, total;
+    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, scans_done, soffsets, cstart, smeta, cmeta, sorted, total;
 };
 
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
@@ -774,6 +799,7 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.ccursor = take((size_t)L.nsb * 4);
     L.rcursor = take((size_t)L.nsb * 4);
     L.rflags = take((size_t)L.nsb);
+    L.scans_done = take(4);
     L.soffsets = take((size_t)L.nsb * 4);
     L.cstart = take((size_t)L.nsb * 4);
     L.smeta = take(16);
@@ -826,14 +852,12 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     unsigned* chist = (unsigned*)(ws + L.chist);
     unsigned* ccursor = (unsigned*)(ws + L.ccursor);
     int32_t* soffsets = (int32_t*)(ws + L.soffsets);
-    int32_t* cstart = (int32_t*)(ws + L.cstart);
     int64_t* cmeta = (int64_t*)(ws + L.cmeta);
     uint4* sorted = (uint4*)(ws + L.sorted);
     SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        SC_HIP(hipFuncSetAttribute((const void*)bin_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
         attr_set = true;
     }
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
@@ -841,17 +865,23 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
                        count_lds_bytes(L), s, means2d, radii, CN,
                        L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
     SC_LAUNCH_CHECK();
-    // one launch: tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3];
-    // centre histogram -> spatial-order bucket starts
+    // tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3]: two extra
+    // blocks of the centre-scatter launch (see the kernel)
     ScanJobs jobs;
     jobs.j[0] = ScanJob{(const int*)dgrid_t, C, tile_width, tile_height, isect_offsets, meta_dev, 1};
     jobs.j[1] = ScanJob{(const int*)dgrid_s, C, L.g.stw, L.g.sth, soffsets, meta_dev + 2, 1};
-    jobs.j[2] = ScanJob{(const int*)chist, 1, L.nsb, 1, cstart, cmeta, 0};
-    hipLaunchKernelGGL(bin_scan_kernel, dim3(3), dim3(1024), (size_t)L.nt_cells * 4, s, jobs);
-    SC_LAUNCH_CHECK();
-    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid), dim3(BIN_THREADS), (size_t)L.nsb * 8, s,
+    jobs.j[2] = jobs.j[1];
+    unsigned* scans_done = (unsigned*)(ws + L.scans_done);
+    const size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
+    static bool center_attr = false;
+    if (!center_attr) {
+        SC_HIP(hipFuncSetAttribute((const void*)center_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+        center_attr = true;
+    }
+    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 2), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
-                       depths, (const int32_t*)cstart, ccursor, sorted, (const int64_t*)meta_dev, meta_mirror, seq);
+                       depths, (const unsigned*)chist, ccursor, sorted, cmeta, (int)grid, jobs, scans_done, meta_dev,
+                       meta_mirror, seq);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
