@@ -10,7 +10,7 @@ from collections import defaultdict
 
 OPS = {
     "projection": ["projection_fwd_kernel"],
-    "isect_tiles": ["bin_count_kernel", "bin_scan_kernel", "center_scatter_kernel",
+    "isect_tiles": ["bin_count_kernel", "center_scatter_kernel",
                     "bin_scatter_flat_kernel", "super_sort_kernel", "super_radix_kernel"],
     "spherical_harmonics": ["sh_fwd_kernel"],
     "rasterize_to_pixels": ["raster_pack_kernel", "raster_fwd_wave_kernel", "raster_fwd_v2_kernel",
