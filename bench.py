@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
     ap.add_argument("--no-fused", action="store_true",
                     help="skip the secondary fused rasterization() measurement (keeps profiles of the headline clean)")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd (training-step) measurement")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
     return ap.parse_args()
@@ -210,6 +211,39 @@ def main():
                               "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 4)"}
         del fused_frames
 
+    # SURVEY 8(d) secondary (N = 1 only): forward + backward steps/s at the reference's training resolution
+    # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
+    # groups requiring grad, absgrad on -- the shape of BASELINE config 3.
+    train_line = None
+    if world == 1 and not args.no_train and not args.scene_ply:
+        from street_crafter_amd.scenes import make_camera
+        tw_, th_ = 1600, int(round(1600 * H / W))
+        tcam = make_camera(tw_, th_, 2050.0 * tw_ / 1920.0, 2050.0 * tw_ / 1920.0).to(dev)
+        tscene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)
+        tparams = (tscene.means, tscene.quats, tscene.scales, tscene.opacities, tscene.sh)
+        for t in tparams:
+            t.requires_grad_(True)
+        target = torch.rand(3, th_, tw_, device=dev)
+
+        def train_step():
+            for t in tparams:
+                t.grad = None
+            out = render_gaussians(tscene, tcam, mode="train")
+            ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
+
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_train = min(args.steps, 20)
+        for _ in range(n_train):
+            train_step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        train_line = {"value": n_train / el, "unit": "steps/s", "ms_per_step": el / n_train * 1e3,
+                      "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad"}
+        del tscene, tparams, target
+
     # per-operator device time from the HIP events recorded inside the timed region
     stage_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
     I_mean = sum(n_isects) / max(len(n_isects), 1)
@@ -254,6 +288,8 @@ def main():
         }
         if fused_line is not None:
             line["fused_rasterization"] = fused_line
+        if train_line is not None:
+            line["train_fwd_bwd"] = train_line
         if world == 1 and not args.no_cpu_baseline:
             import numpy as np
 
