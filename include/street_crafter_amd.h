@@ -209,8 +209,6 @@ int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* 
 int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8_t* out,
                    sc_stream_t stream);
 
-/* unit-test hook: out[w] = sum(in[64 w .. 64 w + 63]) with the backward kernel's DPP wave reduction */
-int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream);
 /* unit-test hook for the backward kernel's transposing reduction (v_permlane32/16_swap + DPP):
  * in [n_waves][16][64] per-lane partial sums, out [n_waves][64]: lane l = 64-lane total of value l >> 2 */
 int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_stream_t stream);
@@ -219,7 +217,7 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
 /* Select a kernel variant at run time (for A/B measurements in one process).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,
  *                     2 = culled + software-pipelined gathers + XCD-aware tile map,
- *                     3 = one wave per tile, 4 pixels per lane, 4 = 3 + packed 64-B records (default)
+ *                     3 = one wave per tile, 4 pixels per lane (default), 4 = 3 + packed 64-B records
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)

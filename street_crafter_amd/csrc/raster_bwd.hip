@@ -184,22 +184,6 @@ __global__ void raster_bwd_kernel(
 //     (66 % of the walked ones on S-1M) cost one lane-test instead of 256 pixel evaluations;
 //   * skip / blend decisions use the forward's pinned arithmetic (raster_common.h).
 // ------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
-    return v + __int_as_float(moved);
-}
-// after this lane 63 holds the sum over the 64 lanes
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of every row holds its row's sum
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // lanes 0..31 get a(l) + a(l + 32), lanes 32..63 get b(l - 32) + b(l)
 __device__ __forceinline__ float swap32_add(float a, float b) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -439,12 +423,6 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     }
 }
 
-// unit-test hook for the DPP reduction: out[w] = sum of in[64 w .. 64 w + 63]
-__global__ __launch_bounds__(64) void test_wave_reduce_kernel(const float* __restrict__ in, float* __restrict__ out) {
-    const float v = wave_sum_to_lane63(in[blockIdx.x * 64 + threadIdx.x]);
-    if (threadIdx.x == 63) out[blockIdx.x] = v;
-}
-
 // unit-test hook for wave_transpose_sum16: in [n_waves][16][64], out [n_waves][64]
 __global__ __launch_bounds__(64) void test_wave_transpose_kernel(const float* __restrict__ in, float* __restrict__ out) {
     float v[16];
@@ -460,15 +438,6 @@ extern "C" int sc_test_wave_transpose_sum16(const float* in, int n_waves, float*
     if (n_waves == 0) return SC_OK;
     if (!in || !out) return SC_EINVAL;
     hipLaunchKernelGGL(test_wave_transpose_kernel, dim3(n_waves), dim3(64), 0, sc_s(stream), in, out);
-    SC_LAUNCH_CHECK();
-    return SC_OK;
-}
-
-extern "C" int sc_test_wave_reduce(const float* in, int n_waves, float* out, sc_stream_t stream) {
-    if (n_waves < 0) return SC_EINVAL;
-    if (n_waves == 0) return SC_OK;
-    if (!in || !out) return SC_EINVAL;
-    hipLaunchKernelGGL(test_wave_reduce_kernel, dim3(n_waves), dim3(64), 0, sc_s(stream), in, out);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -332,23 +332,6 @@ def test_rasterize_other_tile_sizes(ops):
 
 
 # ---- backward ---------------------------------------------------------------------------------
-def test_dpp_wave_reduction_matches_sum():
-    from street_crafter_amd import _lib
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(257, 64, generator=g)
-    x[0] = torch.arange(64, dtype=torch.float32)          # exact: 2016
-    x[1] = 0.0
-    x[1, 17] = 1.0                                         # one lane only
-    xd = x.to(DEV)
-    out = torch.empty(257, device=DEV)
-    _lib.check(lib.sc_test_wave_reduce(xd.data_ptr(), 257, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
-               "sc_test_wave_reduce")
-    got = out.cpu()
-    assert got[0].item() == 2016.0 and got[1].item() == 1.0
-    torch.testing.assert_close(got, x.double().sum(dim=1).float(), rtol=1e-5, atol=1e-5)
-
-
 def test_transposing_wave_reduction_routes_every_lane_once():
     """wave_transpose_sum16 (v_permlane32/16_swap + DPP mirrors): lane l must end with the 64-lane total
     of value l >> 2.  One-hot inputs check the routing exactly (every (value, lane) cell reaches its
