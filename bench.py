@@ -144,17 +144,24 @@ def main():
     gatherer = FrameGatherer(dst=0)
     events = {}
     n_isects = []
+    frame_events = []
 
     def step(s, timed):
         # per-operator HIP events cost ~200 us of host time per frame (10 event pairs), so they are
         # recorded on every 4th timed step only; the kernels and the stream are the same either way
         probe = timed and ((s - args.warmup) % 4 == 0)
         with torch.no_grad():
+            if probe:
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record()
             out = render_gaussians(scene, cams[s], stage_events=events if probe else None,
                                    return_intermediates=probe)
             if probe:
                 n_isects.append(int(out["_isect_ids"].numel()))
             gatherer.submit(s, to_uint8_frame(out["rgb"]))
+            if probe:
+                f1.record()
+                frame_events.append((f0, f1))
 
     for s in range(args.warmup):
         step(s, False)
@@ -286,6 +293,12 @@ def main():
                                "valu_pair_bound": 256 * I_mean},
             "stage_ms": stage_ms,
         }
+        if frame_events:
+            fm = sorted(a.elapsed_time(b) for a, b in frame_events)
+            pick = lambda q: fm[min(len(fm) - 1, int(round(q * (len(fm) - 1))))]
+            line["frame_ms_device"] = {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9), "samples": len(fm),
+                                       "what": "HIP events around whole frames (every 4th timed step, the ones "
+                                               "that also carry the per-operator events)"}
         if fused_line is not None:
             line["fused_rasterization"] = fused_line
         if train_line is not None:
