@@ -569,6 +569,35 @@ def test_rasterization_fused_equals_reference_caller_sequence(ops):
     np.testing.assert_array_equal(_np(meta["radii"]), _np(ref["_radii"]))
 
 
+def test_rasterization_fused_all_culled_and_tiny(ops):
+    """Edge cases through the fused forward: nothing visible (I == 0) gives a black image with alpha 0,
+    and a handful of Gaussians works like the composition."""
+    from street_crafter_amd import rendering
+    cam = make_camera(200, 120, 220.0, 220.0).to(DEV)
+    sc = make_scene(500, seed=3).to(DEV)
+    kw = dict(sh_degree=1, render_mode="RGB+ED", rasterize_mode="antialiased")
+    with torch.no_grad():
+        rc, ra, meta = ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, cam.viewmat[None],
+                                         cam.K[None], 200, 120, near_plane=500.0, far_plane=1000.0, **kw)
+    assert meta["fused"] and int(meta["radii"].abs().sum()) == 0 and meta["flatten_ids"].numel() == 0
+    assert float(rc.abs().sum()) == 0.0 and float(ra.abs().sum()) == 0.0
+    assert meta["isect_ids"].numel() == 0                       # built on demand
+    few = make_scene(3, seed=9, z_range=(3.0, 5.0), scale_range=(0.2, 0.4)).to(DEV)
+    outs = []
+    for fused in (True, False):
+        prev = rendering.set_fused_rasterization(fused)
+        try:
+            with torch.no_grad():
+                outs.append(ops.rasterization(few.means, few.quats, few.scales, few.opacities[:, 0], few.sh,
+                                              cam.viewmat[None], cam.K[None], 200, 120, near_plane=0.001,
+                                              far_plane=1000.0, **kw))
+        finally:
+            rendering.set_fused_rasterization(prev)
+    assert float(outs[0][1].sum()) > 0
+    np.testing.assert_array_equal(_np(outs[0][0]).view(np.uint32), _np(outs[1][0]).view(np.uint32))
+    np.testing.assert_array_equal(_np(outs[0][1]).view(np.uint32), _np(outs[1][1]).view(np.uint32))
+
+
 def test_rasterization_falls_back_to_autograd_operators_when_training(ops):
     sc = make_scene(3000, seed=6, z_range=(1.0, 30.0), scale_range=(0.02, 0.3)).to(DEV)
     cam = make_camera(160, 96, 180.0, 180.0).to(DEV)
