@@ -148,8 +148,8 @@ def main():
 
     def step(s, timed):
         # per-operator HIP events cost ~200 us of host time per frame (10 event pairs), so they are
-        # recorded on every 4th timed step only; the kernels and the stream are the same either way
-        probe = timed and ((s - args.warmup) % 4 == 0)
+        # recorded on every 8th timed step only; the kernels and the stream are the same either way
+        probe = timed and ((s - args.warmup) % 8 == 0)
         with torch.no_grad():
             if probe:
                 f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -297,7 +297,7 @@ def main():
             fm = sorted(a.elapsed_time(b) for a, b in frame_events)
             pick = lambda q: fm[min(len(fm) - 1, int(round(q * (len(fm) - 1))))]
             line["frame_ms_device"] = {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9), "samples": len(fm),
-                                       "what": "HIP events around whole frames (every 4th timed step, the ones "
+                                       "what": "HIP events around whole frames (every 8th timed step, the ones "
                                                "that also carry the per-operator events)"}
         if fused_line is not None:
             line["fused_rasterization"] = fused_line
