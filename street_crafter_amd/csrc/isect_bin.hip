@@ -245,7 +245,7 @@ __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
 }
 
-// The launch also carries the two grid scans (blocks n_center, n_center + 1): they depend on the count
+// The launch also carries the two grid scans (blocks 0 and 1): they depend on the count
 // pass only, like this kernel, so they run beside it instead of in front of it (the separate scan
 // launch sat 13 us on the critical path).  Every centre workgroup builds the bucket starts itself, by a
 // block scan of the 2400-entry centre histogram.  The scan block that finishes second publishes meta.
@@ -253,13 +253,15 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
     const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
-    uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, int n_center, ScanJobs jobs,
+    uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
     unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
     extern __shared__ unsigned lds[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
-    if ((int)blockIdx.x >= n_center) {
-        run_scan_job(jobs.j[blockIdx.x - n_center], reinterpret_cast<int*>(lds), wave_tot, wave_max);
+    // the scan blocks come first in dispatch order, so that meta is published early even when the
+    // centre workgroups need several rounds
+    if (blockIdx.x < 2) {
+        run_scan_job(jobs.j[blockIdx.x], reinterpret_cast<int*>(lds), wave_tot, wave_max);
         if (threadIdx.x == 0) {
             __threadfence();
             if (atomicAdd(scans_done, 1u) == 1u && meta_mirror) {       // both halves of meta are in place
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         }
         return;
     }
+    const int cblock = (int)blockIdx.x - 2;
     unsigned* hist = lds;                    // [n_sbuckets]
     unsigned* gbase = lds + n_sbuckets;      // [n_sbuckets]
     unsigned* cst = lds + 2 * n_sbuckets;    // [n_sbuckets] first slot of each centre bucket in the spatial order
@@ -281,11 +284,11 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         unsigned mx;
         long long run = block_scan_1024(sum, 0u, &tot, &mx, wave_tot, wave_max);
         for (int i = beg; i < end; ++i) { cst[i] = (unsigned)run; run += chist[i]; }
-        if (blockIdx.x == 0 && threadIdx.x == 0) { cmeta[0] = tot; cmeta[1] = 0; }   // number of visible Gaussians
+        if (cblock == 0 && threadIdx.x == 0) { cmeta[0] = tot; cmeta[1] = 0; }   // number of visible Gaussians
     }
     for (int b = threadIdx.x; b < n_sbuckets; b += BIN_THREADS) hist[b] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * BIN_GPB;
+    const int64_t base = (int64_t)cblock * BIN_GPB;
     int cb[BIN_GPT];
     uint4 pay[BIN_GPT];      // tile rectangle (x0 | x1 << 16, y0 | y1 << 16), depth bits, flat id
 #pragma unroll
@@ -880,7 +883,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     }
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 2), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
-                       depths, (const unsigned*)chist, ccursor, sorted, cmeta, (int)grid, jobs, scans_done, meta_dev,
+                       depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
                        meta_mirror, seq);
     SC_LAUNCH_CHECK();
     return SC_OK;
