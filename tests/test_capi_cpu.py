@@ -153,3 +153,20 @@ def test_densification_stats_mirror_cpu():
     st.reset()
     st.add_densification_stats(vp2, vis, W, H)
     assert torch.allclose(st.xyz_gradient_accum["background"][0], torch.tensor([2 ** 0.5, 0.0]))
+
+
+def test_bench_algorithmic_bytes_are_the_survey_formula():
+    """B_alg = 197 N + 88 I + 24 P + 4 T for K = 4; the per-operator split bench.py uses for
+    `roofline.achieved` must add up to it (341 N for K = 16)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from street_crafter_amd.pipeline import algorithmic_bytes
+    N, I, W, H = 1_000_000, 19_753_547, 1920, 1280
+    P, T = W * H, 120 * 80
+    for K, per_gauss in ((4, 197), (16, 341)):
+        total = sum(bench.stage_algorithmic_bytes(s, N, I, P, T, K) for s in
+                    ("projection", "isect_tiles", "isect_offset_encode", "spherical_harmonics", "rasterize_to_pixels"))
+        assert total == per_gauss * N + 88 * I + 24 * P + 4 * T
+        assert algorithmic_bytes(N, I, W, H, 16, K) == total
