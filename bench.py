@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
     ap.add_argument("--raster-variant", type=int, default=None)
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="skip the secondary measurement with two frames in flight on two HIP streams")
     ap.add_argument("--no-fused", action="store_true",
                     help="skip the secondary fused rasterization() measurement (keeps profiles of the headline clean)")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd (training-step) measurement")
@@ -218,6 +220,41 @@ def main():
                               "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 4)"}
         del fused_frames
 
+    # Secondary (N = 1 only): the same K frames with TWO frames in flight, frame f on HIP stream f % 2.
+    # Frames are independent (that is what the multi-GPU sharding relies on); the second stream lets the
+    # latency-bound intersection kernels of one frame run under the VALU-bound rasterizer of the other.
+    # Not the headline: with overlapped frames per-operator durations (and so `roofline`) lose their meaning.
+    overlap_line = None
+    if world == 1 and not args.no_overlap:
+        two = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+        def timed_overlapped(fn):
+            for s in range(args.warmup):
+                with torch.cuda.stream(two[s % 2]):
+                    fn(s)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outs = []
+            for s in range(args.warmup, total_steps):
+                with torch.cuda.stream(two[s % 2]):
+                    outs.append(fn(s))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1, outs
+
+        def caller_step(s):
+            with torch.no_grad():
+                return to_uint8_frame(render_gaussians(scene, cams[s])["rgb"])
+
+        el, outs = timed_overlapped(caller_step)
+        overlap_line = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
+                        "frames_identical_to_single_stream": bool(all(torch.equal(a, b) for a, b in zip(frames, outs))),
+                        "what": "reference caller sequence, two frames in flight on two HIP streams"}
+        del outs
+        if fused_line is not None:
+            el, outs = timed_overlapped(fused_step)
+            overlap_line["fused_rasterization"] = {"value": args.steps / el, "ms_per_step": el / args.steps * 1e3}
+            del outs
+
     # SURVEY 8(d) secondary (N = 1 only): forward + backward steps/s at the reference's training resolution
     # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
     # groups requiring grad, absgrad on -- the shape of BASELINE config 3.
@@ -301,6 +338,8 @@ def main():
                                                "that also carry the per-operator events)"}
         if fused_line is not None:
             line["fused_rasterization"] = fused_line
+        if overlap_line is not None:
+            line["two_frames_in_flight"] = overlap_line
         if train_line is not None:
             line["train_fwd_bwd"] = train_line
         if world == 1 and not args.no_cpu_baseline:
