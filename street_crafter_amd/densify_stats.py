@@ -14,7 +14,7 @@ training benchmark, with the same per-model slicing (`graph_gaussian_range`) the
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import torch
 

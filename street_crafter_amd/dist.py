@@ -10,7 +10,7 @@ No data-path collective exists besides this gather: the shards are independent (
 """
 from __future__ import annotations
 
-from typing import Callable, Iterable, List, Optional
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist

@@ -15,7 +15,7 @@ No GPU is involved (BASELINE config 0: "CPU/numpy (plumbing, no GPU)").
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, Tuple
 
 import numpy as np
 
