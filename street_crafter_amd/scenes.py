@@ -89,6 +89,32 @@ def make_scene(n, sh_degree=1, seed=SEED, x_span=0.55, y_span=0.37, z_range=(2.0
                  opac.contiguous(), sh.contiguous(), sh_degree)
 
 
+def make_scene_portable(n, sh_degree=1, seed=SEED, x_span=0.55, y_span=0.37, z_range=(2.0, 80.0),
+                        scale_range=(0.005, 0.15)):
+    """Same distributions as make_scene, but bit-identical on every host: torch's CPU exp / sigmoid /
+    randn are vectorised differently per instruction set (AVX2 vs AVX-512 builds differ by an ulp, found
+    when a digest made in one container met a scene regenerated on another CPU).  Here every random
+    number is a PCG64 uniform double and the only transcendental, exp, is the scalar libm one; values
+    are rounded to fp32 once at the end.  Used by fixtures that store digests instead of inputs."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    U = lambda lo, hi, *shape: rng.random(shape) * (hi - lo) + lo
+    z = U(z_range[0], z_range[1], n)
+    x = z * U(-x_span, x_span, n)
+    y = z * U(-y_span, y_span, n)
+    lo, hi = math.log(scale_range[0]), math.log(scale_range[1])
+    scales = np.array([math.exp(v) for v in U(lo, hi, n * 3)]).reshape(n, 3)
+    quats = U(-1.0, 1.0, n, 4)                                   # normalised by the kernels themselves
+    quats[np.abs(quats).sum(axis=1) < 1e-3] = [1.0, 0.0, 0.0, 0.0]
+    t = U(-4.5, 4.5, n)                                          # logit-uniform opacity
+    opac = np.array([1.0 / (1.0 + math.exp(-v)) for v in t]).reshape(n, 1)
+    K = (sh_degree + 1) ** 2
+    sh = U(-1.7, 1.7, n, K, 3)
+    sh[:, 1:, :] *= 0.3
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+    return Scene(f(np.stack([x, y, z], axis=-1)), f(quats), f(scales), f(opac), f(sh), sh_degree)
+
+
 def make_edge_case_scene(n=4096, seed=7):
     """Projection edge cases for the golden fixtures: behind the camera,
     nearer than znear, farther than zfar, enormous scales, needle-thin scales, off-screen,

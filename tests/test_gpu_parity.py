@@ -740,6 +740,46 @@ def test_knn_large_vs_ckdtree():
     np.testing.assert_array_equal(_np(distCUDA2(_t(sub))).view(np.uint32), KO.dist_cuda2(sub).view(np.uint32))
 
 
+def test_full_resolution_s100k_against_committed_digest(ops, golden_dir):
+    """S-100k at 1920x1280 against the digest the oracle produced in the build container
+    (tests/golden/s100k_fullres_digest.json, tools/make_golden.py): CRC32 of every integer tensor and of
+    the bit-exact float tensors, 8x8 block means of the image.  No oracle run on the box."""
+    import json
+    import zlib
+    from street_crafter_amd.pipeline import render_gaussians
+    from street_crafter_amd.scenes import make_scene_portable
+    dg = json.load(open(os.path.join(golden_dir, "s100k_fullres_digest.json")))
+    crc_np = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+    sc_cpu = make_scene_portable(100_000)
+    for k, want in dg["scene"]["inputs_crc32"].items():          # the scene generator is host-independent
+        assert crc_np(getattr(sc_cpu, k).numpy()) == want, f"input {k} differs on this host"
+    sc = sc_cpu.to(DEV)
+    cam = make_camera().to(DEV)
+    with torch.no_grad():
+        o = render_gaussians(sc, cam, return_intermediates=True)
+    crc = lambda t: int(zlib.crc32(np.ascontiguousarray(_np(t)).tobytes()) & 0xffffffff)
+    got = {"radii": o["_radii"][0], "means2d": o["_means2d"][0], "depths": o["_depths"][0], "conics": o["_conics"][0],
+           "compensations": o["_compensations"][0], "opacities": o["_opacities"][0],
+           "tiles_per_gauss": o["_tiles_per_gauss"][0], "isect_ids": o["_isect_ids"], "flatten_ids": o["_flatten_ids"],
+           "isect_offsets": o["_isect_offsets"], "colors": o["_colors"][0]}
+    assert o["_isect_ids"].numel() == dg["n_isects"]
+    for k, t in got.items():
+        assert crc(t) == dg["crc32"][k], k
+    img = np.concatenate([_np(o["_render_colors"])[0], _np(o["_render_alphas"])[0]], axis=-1).astype(np.float64)
+    H, W = img.shape[:2]
+    stable = np.ones((H, W), bool)
+    yx = np.asarray(dg["unstable_yx"], dtype=np.int64).reshape(-1, 2)
+    stable[yx[:, 0], yx[:, 1]] = False           # threshold-unstable pixels (listed by the oracle) are left out
+    assert (~stable).mean() < 0.005
+    img[~stable] = 0.0
+    cnt = stable.reshape(H // 160, 160, W // 240, 240).sum(axis=(1, 3))
+    blocks = img.reshape(H // 160, 160, W // 240, 240, 5).sum(axis=(1, 3)) / cnt[..., None]
+    want = np.asarray(dg["image_block_means_over_stable_pixels"])
+    # colour / alpha block means within 2e-6; the depth channel (values up to 80) relative
+    np.testing.assert_allclose(blocks[..., [0, 1, 2, 4]], want[..., [0, 1, 2, 4]], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(blocks[..., 3], want[..., 3], rtol=2e-6, atol=1e-5)
+
+
 # ---- full-size, size-independent properties ------------------------------------------------------
 def test_full_size_properties_1m(ops):
     """BASELINE config: 1 M Gaussians, 1920x1280.  Oracle for the streaming/integer stages

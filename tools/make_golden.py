@@ -92,6 +92,39 @@ def oracle_vectors():
                         tiny=pts[:3], out_tiny=KO.dist_cuda2(pts[:3]))
 
 
+def full_size_digest():
+    """S-100k at the full 1920x1280 resolution, stored as seed + digests (CRC32 of the
+    raw bytes of every integer / bit-exact float tensor, a coarse 8x8-block summary of the image), so the
+    GPU test can check a full-resolution frame without running the oracle on the box."""
+    import json
+    import zlib
+    from oracle import gsplat_oracle as O
+    from street_crafter_amd.scenes import make_camera, make_scene_portable
+    sc = make_scene_portable(100_000)          # bit-identical inputs on every host (see its docstring)
+    cam = make_camera()
+    crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+    r = O.render_frame(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(), sc.sh.numpy(),
+                       cam.viewmat.numpy(), cam.K.numpy(), cam.width, cam.height, sc.sh_degree,
+                       cam_center=cam.camera_center.numpy(), near_plane=cam.znear, far_plane=cam.zfar,
+                       return_unstable=True)
+    img = np.concatenate([r["render_colors"][0], r["render_alphas"][0]], axis=-1).astype(np.float64)   # [H,W,5]
+    H, W = img.shape[:2]
+    # pixels within 2e-5 (relative) of a hard threshold may flip on a 1-ulp exp difference -- numpy's own
+    # exp differs by an ulp between AVX2 and AVX-512 hosts -- so they are listed and left out of the means
+    stable = ~r["unstable"][0]
+    img[~stable] = 0.0
+    cnt = stable.reshape(H // 160, 160, W // 240, 240).sum(axis=(1, 3))
+    blocks = img.reshape(H // 160, 160, W // 240, 240, 5).sum(axis=(1, 3)) / cnt[..., None]  # [8,8,5]
+    d = {"scene": {"n": 100000, "generator": "scenes.make_scene_portable", "width": cam.width, "height": cam.height,
+                   "inputs_crc32": {k: crc(getattr(sc, k).numpy()) for k in ("means", "quats", "scales", "opacities", "sh")}},
+         "n_isects": int(r["isect_ids"].shape[0]),
+         "crc32": {k: crc(r[k]) for k in ("radii", "means2d", "depths", "conics", "compensations", "opacities",
+                                          "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "colors")},
+         "unstable_yx": np.argwhere(~stable).astype(int).tolist(),
+         "image_block_means_over_stable_pixels": np.round(blocks, 8).tolist()}
+    json.dump(d, open(os.path.join(GOLD, "s100k_fullres_digest.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if os.path.isdir(REF):
@@ -99,5 +132,6 @@ if __name__ == "__main__":
     else:
         print("reference not present: *_ref.npz left untouched")
     oracle_vectors()
+    full_size_digest()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
