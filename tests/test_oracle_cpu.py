@@ -181,3 +181,28 @@ def test_algorithmic_bytes_formula():
     n, i = 1_000_000, 8_000_000
     assert algorithmic_bytes(n, i, 1920, 1280) == 197 * n + 88 * i + 24 * 1920 * 1280 + 4 * 9600
     assert algorithmic_bytes(n, 0, 1920, 1280, sh_bases=16) - 24 * 1920 * 1280 - 4 * 9600 == 341 * n
+
+
+def test_oracle_reproduces_full_resolution_digest(golden_dir):
+    """The streaming / integer stages of the oracle on S-100k at 1920x1280 against the committed digest
+    (tests/golden/s100k_fullres_digest.json): a regression guard for the oracle itself, and the CPU half of
+    the cross-host check whose GPU half is test_full_resolution_s100k_against_committed_digest."""
+    import json
+    import zlib
+    from street_crafter_amd.scenes import make_camera, make_scene_portable
+    dg = json.load(open(os.path.join(golden_dir, "s100k_fullres_digest.json")))
+    crc = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
+    sc = make_scene_portable(100_000)
+    for k, want in dg["scene"]["inputs_crc32"].items():
+        assert crc(getattr(sc, k).numpy()) == want, k
+    cam = make_camera()
+    radii, m2, d, con, comp = O.fully_fused_projection(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(),
+                                                       cam.viewmat.numpy(), cam.K.numpy(), cam.width, cam.height,
+                                                       near_plane=cam.znear, far_plane=cam.zfar)
+    tpg, ids, fids = O.isect_tiles(m2[None], radii[None], d[None], 16, 120, 80, n_cameras=1)
+    off = O.isect_offset_encode(ids, 1, 120, 80)
+    got = {"radii": radii, "means2d": m2, "depths": d, "conics": con, "compensations": comp,
+           "tiles_per_gauss": tpg[0], "isect_ids": ids, "flatten_ids": fids, "isect_offsets": off}
+    assert ids.shape[0] == dg["n_isects"]
+    for k, a in got.items():
+        assert crc(a) == dg["crc32"][k], k
