@@ -75,16 +75,33 @@ class FrameGatherer:
 
 
 def render_sharded(n_frames: int, render_frame: Callable[[int], torch.Tensor], dst: int = 0,
-                   group=None) -> Optional[List[torch.Tensor]]:
+                   group=None, frames_in_flight: int = 1) -> Optional[List[torch.Tensor]]:
     """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
     (None elsewhere).  n_frames must be a multiple of the world size (every round is a full
-    gather); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device."""
+    gather); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device.
+
+    frames_in_flight > 1 (HIP devices only): this rank's frames alternate over that many HIP streams, so
+    the latency-bound intersection kernels of one frame run under the rasterizer of another (+20 % frames/s
+    with 2 on S-1M, identical images; bench.py `two_frames_in_flight`).  Frames are independent, every
+    operator launches on torch's current stream, and the gather of a frame is enqueued on its stream."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if n_frames % world:
         raise ValueError(f"n_frames={n_frames} must be a multiple of world size {world}")
     g = FrameGatherer(dst, group)
+    streams = None
+    if frames_in_flight > 1 and torch.cuda.is_available():
+        streams = [torch.cuda.Stream() for _ in range(int(frames_in_flight))]
+        for st in streams:
+            st.wait_stream(torch.cuda.current_stream())
     for r, f in enumerate(frames_for_rank(n_frames, rank, world)):
-        g.submit(r, render_frame(f))
+        if streams is None:
+            g.submit(r, render_frame(f))
+        else:
+            with torch.cuda.stream(streams[r % len(streams)]):
+                g.submit(r, render_frame(f))
+    if streams is not None:
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
     frames = g.drain()
     return frames if rank == dst else None

@@ -669,6 +669,27 @@ def test_densification_statistics_consumer_vs_oracle(ops):
         assert np.isfinite(g_abs).all()
 
 
+def test_render_sharded_two_frames_in_flight_is_identical(ops):
+    """dist.render_sharded with frames alternating over two HIP streams returns the same uint8 frames as
+    the sequential loop (single process: the gather is the identity)."""
+    from street_crafter_amd.dist import render_sharded, to_uint8_frame
+    from street_crafter_amd.pipeline import render_gaussians
+    sc = make_scene(60_000, seed=12).to(DEV)
+    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.02 * i, shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(6)]
+
+    def frame(f):
+        with torch.no_grad():
+            return to_uint8_frame(render_gaussians(sc, cams[f])["rgb"])
+
+    seq = render_sharded(6, frame)
+    ovl = render_sharded(6, frame, frames_in_flight=2)
+    torch.cuda.synchronize()
+    assert len(seq) == len(ovl) == 6
+    for a, b in zip(seq, ovl):
+        assert a.dtype == torch.uint8 and a.shape == (400, 640, 3) and torch.equal(a, b)
+    assert not torch.equal(seq[0], seq[5])
+
+
 def test_scene_files_drive_the_renderer(ops, tmp_path):
     """a scene written in the reference's PLY layout (background + a posed actor with Fourier
     colour), read back and composed, renders bit-identically to the in-memory composition; and an actor
