@@ -1,0 +1,42 @@
+"""Soak: many frames through both paths; memory must stay flat, frames of the same camera identical."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from gsplat.rendering import rasterization  # noqa: E402
+from street_crafter_amd.dist import to_uint8_frame  # noqa: E402
+from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+scene = make_scene(300_000).to("cuda")
+cams = [make_camera(1280, 720, 1400.0, 1400.0, yaw=0.01 * i).to("cuda") for i in range(4)]
+op1 = scene.opacities[:, 0].contiguous()
+ref = {}
+peak = []
+with torch.no_grad():
+    for i in range(N):
+        cam = cams[i % 4]
+        if i % 2 == 0:
+            f = to_uint8_frame(render_gaussians(scene, cam)["rgb"])
+        else:
+            rc, _, _ = rasterization(scene.means, scene.quats, scene.scales, op1, scene.sh, cam.viewmat[None], cam.K[None],
+                                     1280, 720, near_plane=cam.znear, far_plane=cam.zfar, sh_degree=1,
+                                     render_mode="RGB+ED", rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
+            f = to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1))
+        k = i % 4
+        if k in ref:
+            if i % 97 == 0:
+                assert torch.equal(f, ref[k]), f"frame {i} differs"
+        else:
+            ref[k] = f.clone()
+        if i % 500 == 0:
+            torch.cuda.synchronize()
+            peak.append(torch.cuda.memory_allocated())
+            print(i, "allocated MB", peak[-1] / 2**20, "reserved MB", torch.cuda.memory_reserved() / 2**20, flush=True)
+torch.cuda.synchronize()
+assert max(peak[1:]) - min(peak[1:]) < 64 * 2**20, peak
+print("soak ok")
