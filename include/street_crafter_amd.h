@@ -155,8 +155,8 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      int32_t* last_ids /* nullable: only the backward pass reads it */,
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,N,D) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
-/* scratch for the packed-record fast path (64 B per (camera, splat)); without it the kernels gather
- * from the four parameter arrays directly */
+/* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a
+ * kernel with scratch needs no ABI change) */
 size_t sc_rasterize_workspace_bytes(int C, int N, int D);
 /* Gradient outputs must be ZERO-FILLED by the caller (the kernel accumulates with atomics).
  * v_means2d_abs nullable (absgrad). */
@@ -215,9 +215,8 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
- *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats), 1 = culled,
- *                     2 = culled + software-pipelined gathers + XCD-aware tile map,
- *                     3 = one wave per tile, 4 pixels per lane (default), 4 = 3 + packed 64-B records
+ *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats; generic fallback / cross-check),
+ *                     3 = one wave per tile, 4 pixels per lane, exact tile-level cull (default)
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)

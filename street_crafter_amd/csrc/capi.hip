@@ -35,7 +35,7 @@ extern "C" int sc_set_option(const char* key, int value) {
         return prev;
     }
     if (strcmp(key, "raster_fwd") == 0) {
-        if (value < 0 || value > 4) return SC_EINVAL;
+        if (value != 0 && value != 3) return SC_EINVAL;
         const int prev = g_sc_raster_fwd_variant;
         g_sc_raster_fwd_variant = value;
         return prev;

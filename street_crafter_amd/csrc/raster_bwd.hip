@@ -44,9 +44,9 @@ __global__ void raster_bwd_kernel(
     const int tr = threadIdx.y * blockDim.x + threadIdx.x;
     const int lane = tr & 63;
 
-    const int range_start = isect_offsets[tflat];
     const int total_tiles = gridDim.z * tile_width * tile_height;
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    int range_start, range_end;
+    sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
 
     const float T_final = inside ? 1.0f - render_alphas[pix] : 1.0f;
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const int lane = threadIdx.x;
     const int px0_i = txi * 16 + 4 * (lane & 3), py_i = tyi * 16 + (lane >> 2);
     const float py = (float)py_i + 0.5f;
-    const int range_start = isect_offsets[tflat];
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    int range_start, range_end;
+    sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     if (range_end <= range_start) return;
 
     // per-pixel state in pairs (pixels 2p, 2p+1): x centre, running transmittance, T_final (v_alpha - bg.v_c),

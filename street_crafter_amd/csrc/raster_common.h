@@ -53,6 +53,17 @@ __device__ __forceinline__ int sc_safe_id(int g, int n_splats) {
     return ((unsigned)g < (unsigned)n_splats) ? g : -1;
 }
 
+// isect_offsets come from the caller too: a tile's [start, end) is clamped into [0, n_isects], so
+// corrupt offsets (negative, past the end, decreasing) can shorten or empty a tile's list but never
+// turn into an out-of-bounds read of flatten_ids.
+__device__ __forceinline__ void sc_tile_range(const int32_t* __restrict__ isect_offsets, int tflat,
+                                              int total_tiles, int n_isects, int& range_start, int& range_end) {
+    const int s = isect_offsets[tflat];
+    const int e = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    range_start = min(max(s, 0), n_isects);
+    range_end = min(max(e, range_start), n_isects);
+}
+
 // ---- exact tile-level cull, shared by forward and backward ------------------------------------
 // Minimum of q(x,y) = 0.5*(A x^2 + C y^2) + B x y  over the rectangle [x0,x1] x [y0,y1]
 // (coordinates relative to the splat centre).  q is a convex quadratic when the conic is

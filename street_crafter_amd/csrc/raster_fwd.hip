@@ -2,14 +2,13 @@
 // Replaces gsplat.rendering.rasterize_to_pixels as called at
 // street_gaussian/models/street_gaussian_renderer.py:267-280 (semantics: SURVEY.md A.5).
 //
-// Three variants, selectable at run time with sc_set_option("raster_fwd", v) for A/B runs:
-//   0  reference-shaped: one lane per pixel, every lane evaluates every splat of the tile.
-//   1  culled (tile_size 16): while a batch is staged into LDS each staging lane tests
-//      its splat's alpha >= 1/255 ellipse against the tile rectangle (an exact, conservative
-//      test) and the batch is compacted with a wave ballot + prefix sum, so the per-pixel loop
-//      only walks splats that can touch the tile.  Splats that are dropped would have been
-//      skipped by every pixel (alpha < 1/255 leaves T, the colour sums and last_ids untouched),
-//      so the output is identical to variant 0.
+// Two kernels, selectable at run time with sc_set_option("raster_fwd", v):
+//   0  reference-shaped: one lane per pixel, every lane evaluates every splat of the tile; any
+//      tile_size <= 32 and any channel count <= 32.  Generic fallback and on-GPU cross-check.
+//   3  (default; tile 16, 3 or 4 channels) one wave per tile with an exact tile-level cull: see
+//      raster_fwd_wave_kernel.  Bit-identical to 0 (same pinned arithmetic, raster_common.h).
+// (Round 1 also carried a 4-wave culled kernel, its software-pipelined form and a packed-record
+//  variant, numbered 1, 2 and 4; all measured slower -- DESIGN.md, "Tried and dropped" -- and removed.)
 // The blend itself uses v_exp_f32 (fast exp) and FMA contraction: pixels agree with the oracle
 // to ~1e-6 relative, not bitwise (tolerance stated in tests/test_gpu_parity.py).
 #include "raster_common.h"
@@ -59,9 +58,9 @@ __global__ void raster_fwd_ref_kernel(
         return;
     }
 
-    const int range_start = isect_offsets[tflat];
     const int total_tiles = gridDim.z * tile_width * tile_height;
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    int range_start, range_end;
+    sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
 
     float T = 1.0f;
@@ -123,321 +122,6 @@ __global__ void raster_fwd_ref_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// variant 1: culled, tile 16x16, 256 lanes = 4 waves, CDIM in {3,4}
-// ------------------------------------------------------------------------------------------
-// (min_quad_on_rect / splat_misses_rect: raster_common.h, shared with the backward kernel)
-template <int CDIM>
-__global__ __launch_bounds__(256) void raster_fwd_cull_kernel(
-    const float* __restrict__ means2d, const float* __restrict__ conics,
-    const float* __restrict__ colors, const float* __restrict__ opacities,
-    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
-    int width, int height, int tile_width, int tile_height,
-    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg) {
-    constexpr int B = 256;
-    __shared__ float4 xyoa_s[B];      // mx, my, opac, conic.a
-    __shared__ float4 bck_s[B];       // conic.b, conic.c, k (sorted index, as int bits), -
-    __shared__ float4 col_s[B];       // colour channels
-    __shared__ int wave_cnt_s[4];
-
-    const int cam = blockIdx.z;
-    const int tile_id = blockIdx.y * tile_width + blockIdx.x;
-    const int tflat = cam * tile_width * tile_height + tile_id;
-    const int tr = threadIdx.x;
-    const int lane = tr & 63, wave = tr >> 6;
-    // lane -> pixel: wave w covers rows 4w..4w+3, 16 pixels per row
-    const int lx = tr & 15, ly = tr >> 4;
-    const int px_i = blockIdx.x * 16 + lx, py_i = blockIdx.y * 16 + ly;
-    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
-    const bool inside = (px_i < width) && (py_i < height);
-    const int64_t pix = ((int64_t)cam * height + py_i) * width + px_i;
-
-    if (tile_masks && !tile_masks[tflat]) {
-        if (inside) {
-#pragma unroll
-            for (int d = 0; d < CDIM; ++d)
-                render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
-            render_alphas[pix] = 0.f;
-            if (last_ids) last_ids[pix] = 0;
-        }
-        return;
-    }
-    const int range_start = isect_offsets[tflat];
-    const int total_tiles = gridDim.z * tile_width * tile_height;
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
-    const int num_batches = (range_end - range_start + B - 1) / B;
-
-    // tile rectangle in pixel-centre coordinates (only pixels inside the image count)
-    const float rx0 = (float)(blockIdx.x * 16) + 0.5f;
-    const float ry0 = (float)(blockIdx.y * 16) + 0.5f;
-    const float rx1 = (float)min(blockIdx.x * 16 + 15, width - 1) + 0.5f;
-    const float ry1 = (float)min(blockIdx.y * 16 + 15, height - 1) + 0.5f;
-
-    float T = 1.0f;
-    int cur_idx = 0;
-    bool done = !inside;
-    float pix_out[CDIM];
-#pragma unroll
-    for (int d = 0; d < CDIM; ++d) pix_out[d] = 0.f;
-
-    for (int b = 0; b < num_batches; ++b) {
-        if (__syncthreads_count(done) >= B) break;
-        const int batch_start = range_start + B * b;
-        const int idx = batch_start + tr;
-        // ---- stage + cull -------------------------------------------------------------------
-        bool keep = false;
-        float4 v0, v1, v2;
-        const int g = (idx < range_end) ? sc_safe_id(flatten_ids[idx], N) : -1;
-        if (g >= 0) {
-            const float2 xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-            const float* cn = conics + (int64_t)g * 3;
-            const float ca = cn[0], cb = cn[1], cc = cn[2];
-            const float op = opacities[g];
-            keep = !splat_misses_rect(ca, cb, cc, op, rx0 - xy.x, rx1 - xy.x, ry0 - xy.y, ry1 - xy.y);
-            const ScSplat sp = sc_prescale(xy.x, xy.y, ca, cb, cc, op);
-            v0 = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
-            v1 = make_float4(sp.B2, sp.C2, __int_as_float(idx), 0.f);
-            if (keep) {
-                const float* c = colors + (int64_t)g * CDIM;
-                v2 = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wave_cnt_s[wave] = __popcll(m);
-        __syncthreads();   // also orders the previous batch's LDS reads before this batch's writes
-        int base = 0, bsz = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int c = wave_cnt_s[w];
-            if (w < wave) base += c;
-            bsz += c;
-        }
-        if (keep) {
-            const int slot = base + __popcll(m & sc_lanemask_lt());
-            xyoa_s[slot] = v0;
-            bck_s[slot] = v1;
-            col_s[slot] = v2;
-        }
-        __syncthreads();
-        // ---- blend ---------------------------------------------------------------------------
-        if (dbg & 1) bsz = 0;
-        for (int t = 0; (t < bsz) && !done; ++t) {
-            const float4 a = xyoa_s[t];
-            const float4 bc = bck_s[t];
-            const float dx = a.x - px, dy = a.y - py;
-            const float sigma = sc_sigma2(a.w, sc_row_b(bc.x, dy), sc_row_q(bc.y, dy), dx);
-            const float alpha = sc_alpha2(a.z, sigma);
-            if (!sc_valid(sigma, alpha)) continue;
-            const float next_T = sc_next_T(T, alpha);
-            if (next_T <= SC_T_EPS) { done = true; break; }
-            const float vis = __fmul_rn(alpha, T);
-            const float4 c = col_s[t];
-            pix_out[0] = __fmaf_rn(c.x, vis, pix_out[0]);
-            pix_out[1] = __fmaf_rn(c.y, vis, pix_out[1]);
-            pix_out[2] = __fmaf_rn(c.z, vis, pix_out[2]);
-            if (CDIM > 3) pix_out[3] = __fmaf_rn(c.w, vis, pix_out[3]);
-            cur_idx = __float_as_int(bc.z);
-            T = next_T;
-        }
-    }
-    if (inside) {
-        render_alphas[pix] = 1.0f - T;
-        if (CDIM == 4) {
-            float4 o = make_float4(pix_out[0], pix_out[1], pix_out[2], pix_out[3]);
-            if (backgrounds) {
-                o.x += T * backgrounds[cam * 4 + 0]; o.y += T * backgrounds[cam * 4 + 1];
-                o.z += T * backgrounds[cam * 4 + 2]; o.w += T * backgrounds[cam * 4 + 3];
-            }
-            *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
-        } else {
-#pragma unroll
-            for (int d = 0; d < CDIM; ++d)
-                render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
-        }
-        if (last_ids) last_ids[pix] = cur_idx;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// variant 2: variant 1's algorithm, restructured for latency:
-//   * 1-D grid with an XCD-aware tile map: blocks b, b+8, b+16.. share an XCD (and its 4 MiB L2),
-//     so each XCD gets one contiguous band of tile rows and the splat parameters its tiles gather
-//     stay L2-resident (speed only: any placement is correct);
-//   * the gathers are software-pipelined through registers: while batch b is blended, the
-//     parameters of batch b+1 and the ids of batch b+2 are already in flight;
-//   * the blend loop is predicated (no per-lane continue/break), prefetches the next LDS record,
-//     and leaves as soon as every lane of the WAVE is done.
-// Same arithmetic (raster_common.h) -> bit-identical output to variants 0 and 1.
-// ------------------------------------------------------------------------------------------
-template <int CDIM>
-__global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
-    const float* __restrict__ means2d, const float* __restrict__ conics,
-    const float* __restrict__ colors, const float* __restrict__ opacities,
-    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
-    int width, int height, int tile_width, int tile_height, int total_tiles,
-    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
-    float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg) {
-    constexpr int B = 256;
-    __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
-    __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
-    __shared__ float4 col_s[B + 1];       // colour channels
-    __shared__ int wave_cnt_s[4];
-
-    // XCD-aware bijective remap of the linear block id (guide T1)
-    int tflat;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tiles_per_cam = tile_width * tile_height;
-    const int cam = tflat / tiles_per_cam;
-    const int tile_id = tflat - cam * tiles_per_cam;
-    const int tyi = tile_id / tile_width, txi = tile_id - tyi * tile_width;
-    const int tr = threadIdx.x;
-    const int lane = tr & 63, wave = tr >> 6;
-    const int lx = tr & 15, ly = tr >> 4;
-    const int px_i = txi * 16 + lx, py_i = tyi * 16 + ly;
-    const float px = (float)px_i + 0.5f, py = (float)py_i + 0.5f;
-    const bool inside = (px_i < width) && (py_i < height);
-    const int64_t pix = ((int64_t)cam * height + py_i) * width + px_i;
-
-    if (tile_masks && !tile_masks[tflat]) {
-        if (inside) {
-#pragma unroll
-            for (int d = 0; d < CDIM; ++d)
-                render_colors[pix * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
-            render_alphas[pix] = 0.f;
-            if (last_ids) last_ids[pix] = 0;
-        }
-        return;
-    }
-    const int range_start = isect_offsets[tflat];
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
-    const int num_batches = (range_end - range_start + B - 1) / B;
-
-    const float rx0 = (float)(txi * 16) + 0.5f;
-    const float ry0 = (float)(tyi * 16) + 0.5f;
-    const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
-    const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
-
-    float T = 1.0f;
-    int cur_idx = 0;
-    bool done = !inside;
-    float pix_out[CDIM];
-#pragma unroll
-    for (int d = 0; d < CDIM; ++d) pix_out[d] = 0.f;
-
-    // ---- pipeline prologue: parameters of batch 0, id of batch 1 ----------------------------------
-    float2 p_xy = make_float2(0.f, 0.f);
-    float p_a = 0.f, p_b = 0.f, p_c = 0.f, p_op = 0.f;
-    float4 p_col = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool p_live = false;
-    int g_next = -1;
-    {
-        const int idx0 = range_start + tr;
-        const int g = (idx0 < range_end) ? sc_safe_id(flatten_ids[idx0], N) : -1;
-        if (g >= 0) {
-            p_xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-            const float* cn = conics + (int64_t)g * 3;
-            p_a = cn[0]; p_b = cn[1]; p_c = cn[2];
-            p_op = opacities[g];
-            const float* c = colors + (int64_t)g * CDIM;
-            p_col = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-            p_live = true;
-        }
-        const int idx1 = idx0 + B;
-        if (idx1 < range_end) g_next = sc_safe_id(flatten_ids[idx1], N);
-    }
-
-    for (int b = 0; b < num_batches; ++b) {
-        if (__syncthreads_count(done) >= B) break;
-        const int batch_start = range_start + B * b;
-        // ---- cull + compact batch b (its parameters are in registers) -----------------------------
-        bool keep = false;
-        if (p_live)
-            keep = !splat_misses_rect(p_a, p_b, p_c, p_op, rx0 - p_xy.x, rx1 - p_xy.x, ry0 - p_xy.y, ry1 - p_xy.y);
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wave_cnt_s[wave] = __popcll(m);
-        __syncthreads();
-        int base = 0, bsz = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int c = wave_cnt_s[w];
-            if (w < wave) base += c;
-            bsz += c;
-        }
-        if (keep) {
-            const int slot = base + __popcll(m & sc_lanemask_lt());
-            const ScSplat sp = sc_prescale(p_xy.x, p_xy.y, p_a, p_b, p_c, p_op);
-            xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2);
-            bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(batch_start + tr), 0.f);
-            col_s[slot] = p_col;
-        }
-        __syncthreads();
-        // ---- put batch b+1's parameters and batch b+2's ids in flight ------------------------------
-        {
-            p_live = g_next >= 0;
-            if (p_live) {
-                const int g = g_next;
-                p_xy = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-                const float* cn = conics + (int64_t)g * 3;
-                p_a = cn[0]; p_b = cn[1]; p_c = cn[2];
-                p_op = opacities[g];
-                const float* c = colors + (int64_t)g * CDIM;
-                p_col = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-            }
-            const int idx2 = batch_start + 2 * B + tr;
-            g_next = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
-        }
-        // ---- blend batch b ---------------------------------------------------------------------------
-        if (dbg & 1) bsz = 0;
-        if (bsz > 0) {
-            float4 a = xyoa_s[0], bc = bck_s[0], c = col_s[0];
-            for (int t = 0; t < bsz; ++t) {
-                const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
-                const float dx = a.x - px, dy = a.y - py;
-                const float sigma = sc_sigma2(a.w, sc_row_b(bc.x, dy), sc_row_q(bc.y, dy), dx);
-                const float alpha = sc_alpha2(a.z, sigma);
-                const bool valid = !done && sc_valid(sigma, alpha);
-                const float next_T = sc_next_T(T, alpha);
-                const bool term = valid && (next_T <= SC_T_EPS);
-                done = done || term;
-                if (valid && !term) {
-                    const float vis = __fmul_rn(alpha, T);
-                    pix_out[0] = __fmaf_rn(c.x, vis, pix_out[0]);
-                    pix_out[1] = __fmaf_rn(c.y, vis, pix_out[1]);
-                    pix_out[2] = __fmaf_rn(c.z, vis, pix_out[2]);
-                    if (CDIM > 3) pix_out[3] = __fmaf_rn(c.w, vis, pix_out[3]);
-                    cur_idx = __float_as_int(bc.z);
-                    T = next_T;
-                }
-                if (__all(done)) break;
-                a = an; bc = bcn; c = cn;
-            }
-        }
-    }
-    if (inside) {
-        render_alphas[pix] = 1.0f - T;
-        if (CDIM == 4) {
-            float4 o = make_float4(pix_out[0], pix_out[1], pix_out[2], pix_out[3]);
-            if (backgrounds) {
-                o.x += T * backgrounds[cam * 4 + 0]; o.y += T * backgrounds[cam * 4 + 1];
-                o.z += T * backgrounds[cam * 4 + 2]; o.w += T * backgrounds[cam * 4 + 3];
-            }
-            *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
-        } else {
-#pragma unroll
-            for (int d = 0; d < CDIM; ++d)
-                render_colors[pix * CDIM + d] = backgrounds ? pix_out[d] + T * backgrounds[cam * CDIM + d] : pix_out[d];
-        }
-        if (last_ids) last_ids[pix] = cur_idx;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // variant 3: ONE WAVE PER TILE, four pixels per lane (lane l owns pixels x = 4*(l&3)..+3 of row
 // l>>2 of the 16x16 tile).  Measured on variant 2 the blend loop was co-bound by the LDS
 // broadcast reads of the splat record (3 x ds_read_b128 per splat per wave, 4 waves per tile)
@@ -445,17 +129,14 @@ __global__ __launch_bounds__(256) void raster_fwd_v2_kernel(
 // dy-dependent terms are shared by the lane's four pixels, there is no workgroup barrier at all
 // (the workgroup IS the wave), the whole-tile early exit is a single wave vote, and up to 32
 // tiles are resident per CU to hide the gather latency.  The lane stores its four pixels as
-// 64 contiguous bytes.  Same pinned arithmetic -> bit-identical to variants 0-2.
+// 64 contiguous bytes.  Same pinned arithmetic -> bit-identical to variant 0.
 // ------------------------------------------------------------------------------------------
-// PACKED: the splat parameters come from 64-byte records written by raster_pack_kernel (one
-// 64-B transaction per staged splat instead of four or five 4..16-B gathers from four arrays).
 // TRACK: record last_ids (the sorted index of the last splat each pixel blended), needed only by
 // the backward pass; inference launches the variant without it.
-template <int CDIM, bool PACKED, bool TRACK>
+template <int CDIM, bool TRACK>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
-    const float4* __restrict__ recs,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
@@ -502,8 +183,8 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
         }
         return;
     }
-    const int range_start = isect_offsets[tflat];
-    const int range_end = (tflat + 1 < total_tiles) ? isect_offsets[tflat + 1] : n_isects;
+    int range_start, range_end;
+    sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
 
     const float rx0 = (float)(txi * 16) + 0.5f;
@@ -546,20 +227,12 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     bool p_live[SB];
     int g_next[SB];
     auto load_splat = [&](int g, int j) {
-        if constexpr (PACKED) {
-            const float4* r = recs + (int64_t)g * 4;
-            const float4 r0 = r[0], r1 = r[1];
-            p_col[j] = r[2];
-            p_xy[j] = make_float2(r0.x, r0.y);
-            p_op[j] = r0.z; p_a[j] = r0.w; p_b[j] = r1.x; p_c[j] = r1.y;
-        } else {
-            p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
-            const float* cn = conics + (int64_t)g * 3;
-            p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
-            p_op[j] = opacities[g];
-            const float* c = colors + (int64_t)g * CDIM;
-            p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-        }
+        p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
+        const float* cn = conics + (int64_t)g * 3;
+        p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
+        p_op[j] = opacities[g];
+        const float* c = colors + (int64_t)g * CDIM;
+        p_col[j] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
     };
 #pragma unroll
     for (int j = 0; j < SB; ++j) {
@@ -678,28 +351,11 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     }
 }
 
-// 64-byte record per (camera, splat): [mx my op a | b c - - | colour x4 | pad]
-template <int CDIM>
-__global__ __launch_bounds__(256) void raster_pack_kernel(
-    const float* __restrict__ means2d, const float* __restrict__ conics,
-    const float* __restrict__ colors, const float* __restrict__ opacities, int64_t CN,
-    float4* __restrict__ recs) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= CN) return;
-    const float2 xy = *reinterpret_cast<const float2*>(means2d + g * 2);
-    const float* cn = conics + g * 3;
-    const float* c = colors + g * CDIM;
-    float4* r = recs + g * 4;
-    r[0] = make_float4(xy.x, xy.y, opacities[g], cn[0]);
-    r[1] = make_float4(cn[1], cn[2], 0.f, 0.f);
-    r[2] = make_float4(c[0], c[1], c[2], CDIM > 3 ? c[3] : 0.f);
-}
-
 }  // namespace
 
 extern "C" size_t sc_rasterize_workspace_bytes(int C, int N, int D) {
-    if (C <= 0 || N <= 0 || (D != 3 && D != 4)) return 256;
-    return sc_align_up((size_t)C * N * 64, 256);
+    (void)C; (void)N; (void)D;
+    return 256;       // the shipped kernels need no scratch (round 1's packed-record variant did: 64 B x C x N)
 }
 
 static int rasterize_fwd_impl(const float* means2d, const float* conics, const float* colors,
@@ -710,6 +366,7 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
                               int64_t n_isects, float* render_colors, float* render_alphas,
                               int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream,
                               int epilogue) {
+    (void)workspace; (void)ws_bytes;
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
@@ -727,61 +384,14 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     const int kdbg = g_sc_debug[1] | (epilogue ? 0x100 : 0);
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         const int total_tiles = C * tile_width * tile_height;
-        const int64_t CN = (int64_t)C * N;
-        // variant 4: pack the parameters into 64-B records first (needs the workspace)
-        const bool packed = variant == 4 && workspace && ws_bytes >= sc_rasterize_workspace_bytes(C, N, D) &&
-                            n_isects > 0;
-        float4* recs = packed ? (float4*)workspace : nullptr;
-#define SC_LAUNCH_WAVE(CD, PK, TR)                                                                                  \
-    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, PK, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,    \
-                       conics, colors, opacities, (const float4*)recs, backgrounds, tile_masks, NS, width, height,  \
-                       tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,            \
-                       render_colors, render_alphas, last_ids, kdbg)
-        if (packed) {
-            const unsigned pg = (unsigned)((CN + 255) / 256);
-            if (D == 4) {
-                hipLaunchKernelGGL(raster_pack_kernel<4>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
-                                   colors, opacities, CN, recs);
-                if (last_ids) SC_LAUNCH_WAVE(4, true, true); else SC_LAUNCH_WAVE(4, true, false);
-            } else {
-                hipLaunchKernelGGL(raster_pack_kernel<3>, dim3(pg), dim3(256), 0, sc_s(stream), means2d, conics,
-                                   colors, opacities, CN, recs);
-                if (last_ids) SC_LAUNCH_WAVE(3, true, true); else SC_LAUNCH_WAVE(3, true, false);
-            }
-        } else {
-            if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, false, true); else SC_LAUNCH_WAVE(4, false, false); }
-            else { if (last_ids) SC_LAUNCH_WAVE(3, false, true); else SC_LAUNCH_WAVE(3, false, false); }
-        }
+#define SC_LAUNCH_WAVE(CD, TR)                                                                                      \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,        \
+                       conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
+                       tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
+                       render_alphas, last_ids, kdbg)
+        if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
+        else { if (last_ids) SC_LAUNCH_WAVE(3, true); else SC_LAUNCH_WAVE(3, false); }
 #undef SC_LAUNCH_WAVE
-        SC_LAUNCH_CHECK();
-        return SC_OK;
-    }
-    if (variant == 2 && tile_size == 16 && (D == 3 || D == 4)) {
-        const int total_tiles = C * tile_width * tile_height;
-        if (D == 4)
-            hipLaunchKernelGGL(raster_fwd_v2_kernel<4>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
-                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
-                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
-        else
-            hipLaunchKernelGGL(raster_fwd_v2_kernel<3>, dim3(total_tiles), dim3(256), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
-                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects,
-                               render_colors, render_alphas, last_ids, g_sc_debug[1]);
-        SC_LAUNCH_CHECK();
-        return SC_OK;
-    }
-    if (variant >= 1 && tile_size == 16 && (D == 3 || D == 4)) {
-        if (D == 4)
-            hipLaunchKernelGGL(raster_fwd_cull_kernel<4>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
-                               colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
-                               tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
-                               render_alphas, last_ids, g_sc_debug[1]);
-        else
-            hipLaunchKernelGGL(raster_fwd_cull_kernel<3>, grid, dim3(256), 0, sc_s(stream), means2d, conics,
-                               colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
-                               tile_height, isect_offsets, flatten_ids, (int)n_isects, render_colors,
-                               render_alphas, last_ids, g_sc_debug[1]);
         SC_LAUNCH_CHECK();
         return SC_OK;
     }

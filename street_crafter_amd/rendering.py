@@ -404,11 +404,11 @@ class _Rasterize(torch.autograd.Function):
         # last_ids only feeds the backward replay: inference (no input requires grad) skips it
         needs_bwd = any(ctx.needs_input_grad[:5])
         last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev) if needs_bwd else None
-        ws = _ws(lib.sc_rasterize_workspace_bytes(C, N, D), dev)
+        # (the shipped kernels need no scratch: sc_rasterize_workspace_bytes() == 256, nothing is allocated)
         _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
                                         _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
                                         _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-                                        _p(render_colors), _p(render_alphas), _p(last_ids), _p(ws), ws.numel(),
+                                        _p(render_colors), _p(render_alphas), _p(last_ids), None, 0,
                                         _stream(means2d)),
                    "sc_rasterize_fwd")
         e = torch.empty(0, device=dev)
@@ -601,20 +601,19 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                                  torch.zeros(C, 1, device=dev)], dim=-1).contiguous()
     render_colors = torch.empty((C, height, width, 4), dtype=torch.float32, device=dev)
     render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
-    ws = _ws(lib.sc_rasterize_workspace_bytes(C, N, 4), dev)
     args = (_p(means2d), _p(conics), _p(cols), _p(opac), _p(backgrounds), None, C, N, 4, int(width), int(height),
             int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
             _p(render_colors), _p(render_alphas))
     if render_mode == "RGB+ED":
-        rc = lib.sc_rasterize_fwd_ed(*args, _p(ws), ws.numel(), st)
-        if rc == -3:          # a non-wave raster variant is selected: plain launch + the torch post-step
-            _lib.check(lib.sc_rasterize_fwd(*args, None, _p(ws), ws.numel(), st), "sc_rasterize_fwd")
+        rc = lib.sc_rasterize_fwd_ed(*args, None, 0, st)
+        if rc == -3:          # the reference-shaped raster kernel is selected: plain launch + the torch post-step
+            _lib.check(lib.sc_rasterize_fwd(*args, None, None, 0, st), "sc_rasterize_fwd")
             render_colors = torch.cat([render_colors[..., :-1],
                                        render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
         else:
             _lib.check(rc, "sc_rasterize_fwd_ed")
     else:
-        _lib.check(lib.sc_rasterize_fwd(*args, None, _p(ws), ws.numel(), st), "sc_rasterize_fwd")
+        _lib.check(lib.sc_rasterize_fwd(*args, None, None, 0, st), "sc_rasterize_fwd")
     meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
                        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
                        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,

@@ -30,10 +30,7 @@ CONFIGS = [
     ("bucket sort: no rank loop/stores", {"debug2": 2}),
     ("isect radix route", {"isect": "radix"}),
     ("raster variant 0", {"raster_fwd": 0}),
-    ("raster variant 1", {"raster_fwd": 1}),
-    ("raster variant 2", {"raster_fwd": 2}),
     ("raster variant 3", {"raster_fwd": 3}),
-    ("raster variant 4", {"raster_fwd": 4}),
 ]
 
 

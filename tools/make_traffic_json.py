@@ -13,8 +13,7 @@ OPS = {
     "isect_tiles": ["bin_count_kernel", "center_scatter_kernel",
                     "bin_scatter_flat_kernel", "super_sort_kernel", "super_radix_kernel"],
     "spherical_harmonics": ["sh_fwd_kernel"],
-    "rasterize_to_pixels": ["raster_pack_kernel", "raster_fwd_wave_kernel", "raster_fwd_v2_kernel",
-                            "raster_fwd_cull_kernel", "raster_fwd_ref_kernel"],
+    "rasterize_to_pixels": ["raster_fwd_wave_kernel", "raster_fwd_ref_kernel"],
 }
 src, dst, key, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 tot = defaultdict(lambda: defaultdict(float))      # kernel -> counter -> sum over all dispatches (KB)
