@@ -123,11 +123,15 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* 
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
                       const int32_t* isect_offsets, const int64_t* meta_dev,
-                      void* count_workspace /* the one sc_isect_bin_count filled; its scratch counters are
+                      void* count_workspace /* the one sc_isect_bin_count filled: its scratch counters are
                                                consumed by the first launch whose capacities suffice */,
                       int64_t capacity, int64_t rec_capacity, int64_t super_capacity,
                       int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
+/* Re-zero the sort phase's bucket cursors / fallback flags inside `count_workspace`: call before a
+ * SECOND sc_isect_bin_sort of the same count phase (retry after an under-predicted capacity). */
+int sc_isect_bin_reset_cursors(void* count_workspace, int64_t CN, int C, int tile_width, int tile_height,
+                               sc_stream_t stream);
 
 /* ---- a4: offsets (renderer.py:253) ---------------------------------------------------- */
 int sc_isect_offsets(const int64_t* isect_ids, int64_t n_isects, int C, int tile_width,

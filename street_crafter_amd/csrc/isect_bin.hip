@@ -543,8 +543,9 @@ constexpr int BS_MAX_OCC = 48;
 __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
     const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
     Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
-    int64_t rec_capacity, int tile_bits, int cap, int per_thread, unsigned char* __restrict__ needs_radix,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
+    int64_t rec_capacity, int64_t super_capacity, int tile_bits, int cap, int per_thread,
+    unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
+    int dbg) {
     extern __shared__ __align__(16) unsigned char smem[];
     // [B: cap u64][order: cap u16][boff: SS_THREADS*per_thread + 1 u32][table]
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
@@ -554,7 +555,9 @@ __global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
     unsigned long long* table = reinterpret_cast<unsigned long long*>(boff + ((nbk + 2) & ~1));
     __shared__ unsigned red_lo[SS_WAVES], red_hi[SS_WAVES], red_sum[SS_WAVES], red_occ[SS_WAVES];
 
-    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > (int64_t)cap) return;
+    // the SAME three comparisons in every kernel of the sort phase and in the host wrapper
+    // (rendering._bin_launch_ran): a launch either runs in full or not at all
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     const int sb = blockIdx.x;
     const int s = soffsets[sb];
     const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
@@ -713,8 +716,9 @@ __device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ s
 __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
     const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
     Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
-    int64_t rec_capacity, int tile_bits, int id_bits, int cap, const unsigned char* __restrict__ needs_radix,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    int64_t rec_capacity, int64_t super_capacity, int tile_bits, int id_bits, int cap,
+    const unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
+    int32_t* __restrict__ flatten_ids) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);
     unsigned long long* Bb = A + cap;
@@ -722,7 +726,7 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
     __shared__ unsigned h[TS_WAVES][256];
     __shared__ unsigned wtot[TS_WAVES];
     __shared__ unsigned diff_s;
-    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > (int64_t)cap) return;
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     const int t = threadIdx.x;
     for (int sb = blockIdx.x; sb < n_sbuckets; sb += gridDim.x) {
         if (!needs_radix[sb]) continue;              // workgroup-uniform
@@ -812,6 +816,28 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     return L;
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: done once per device, under a mutex
+// (one process may drive several GPUs, and several host threads may enter the library)
+#include <mutex>
+static hipError_t bin_attrs_once() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev]) return hipSuccess;
+    const int a = hipFuncAttributeMaxDynamicSharedMemorySize;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    // (super_sort_kernel also has ~4 KiB of static LDS: stay below 160 KiB in total)
+    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 156 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)super_radix_kernel, (hipFuncAttribute)a, 150 * 1024)) != hipSuccess) return e;
+    done[dev] = true;
+    return hipSuccess;
+}
+
 static inline size_t count_lds_bytes(const BinLayout& L) {
     return (size_t)(L.nt_cells + L.ns_cells + L.nsb) * 4;
 }
@@ -858,11 +884,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     int64_t* cmeta = (int64_t*)(ws + L.cmeta);
     uint4* sorted = (uint4*)(ws + L.sorted);
     SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        attr_set = true;
-    }
+    SC_HIP(bin_attrs_once());
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
                        count_lds_bytes(L), s, means2d, radii, CN,
@@ -876,16 +898,24 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     jobs.j[2] = jobs.j[1];
     unsigned* scans_done = (unsigned*)(ws + L.scans_done);
     const size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
-    static bool center_attr = false;
-    if (!center_attr) {
-        SC_HIP(hipFuncSetAttribute((const void*)center_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-        center_attr = true;
-    }
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 2), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
                        depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
                        meta_mirror, seq);
     SC_LAUNCH_CHECK();
+    return SC_OK;
+}
+
+// Re-zeroes the sort phase's bucket cursors and fallback flags.  Not needed in the normal flow (one
+// memset per frame in sc_isect_bin_count covers them and a launch with too small capacities returns
+// before touching them); the wrapper calls it before any SECOND sc_isect_bin_sort of the same count
+// phase so that a repeated scatter can never start from advanced cursors.
+extern "C" int sc_isect_bin_reset_cursors(void* count_workspace, int64_t CN, int C, int tile_width, int tile_height,
+                                          sc_stream_t stream) {
+    if (!count_workspace || C <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
+    if ((int64_t)C * tile_width * tile_height > BIN_MAX_TILES) return SC_EUNSUPPORTED;
+    const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
+    SC_HIP(hipMemsetAsync((unsigned char*)count_workspace + L.rcursor, 0, L.scans_done - L.rcursor, sc_s(stream)));
     return SC_OK;
 }
 
@@ -923,7 +953,7 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     uint2* records = (uint2*)workspace;
     hipLaunchKernelGGL(bin_scatter_flat_kernel, dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
                        dim3(FLAT_THREADS), (size_t)L.nsb * 8 + FLAT_WAVES * sizeof(FlatTab), s, sorted, cmeta, L.g, L.nsb,
-                       soffsets, meta_dev, capacity, rec_capacity, (int64_t)cap, cursor, records, g_sc_debug[0]);
+                       soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
     const int id_bits = sc_bits_for(CN > 1 ? CN - 1 : 1);
@@ -937,21 +967,15 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     const size_t table_radix = (size_t)((cap + TS_THREADS - 1) / TS_THREADS + 1) * TS_WAVES * 8 + 64;
     const size_t lds_radix = (size_t)cap * 16 + table_radix;
     if (lds_sort > 156 * 1024) return SC_EUNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(hipFuncSetAttribute((const void*)super_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        // (this kernel also has ~4 KiB of static LDS: stay below 160 KiB in total)
-        SC_HIP(hipFuncSetAttribute((const void*)super_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    SC_HIP(bin_attrs_once());
     hipLaunchKernelGGL(super_sort_kernel, dim3(L.nsb), dim3(SS_THREADS), lds_sort, s, (const uint2*)records, soffsets,
-                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, cap, per_thread,
-                       needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
+                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, super_capacity, tile_bits, cap,
+                       per_thread, needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
     SC_LAUNCH_CHECK();
     const int rgrid = L.nsb < 512 ? L.nsb : 512;      // persistent; A/B when no super-tile is flagged: 128 -> 8.5 us, 512 -> 4.8 us
     hipLaunchKernelGGL(super_radix_kernel, dim3(rgrid), dim3(TS_THREADS), lds_radix, s, (const uint2*)records, soffsets,
-                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, tile_bits, id_bits, cap,
-                       (const unsigned char*)needs_radix, isect_ids, flatten_ids);
+                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, super_capacity, tile_bits, id_bits,
+                       cap, (const unsigned char*)needs_radix, isect_ids, flatten_ids);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -237,7 +237,16 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_BIN_LAST_META = {}    # same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
 _PINNED_META = {}      # device index -> [pinned int64[8] the device publishes meta into, its numpy view, seq]
+
+
+def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
+    """True iff a bucket scatter + sort launched with `capacities` = (capacity, rec_capacity, super_capacity)
+    passed the device-side size check, i.e. ran in full.  Must mirror the kernels' test
+    (`meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity`, isect_bin.hip) exactly:
+    sc_isect_bin_sort hands the kernels the SAME unrounded numbers it is given."""
+    return n_isects <= capacities[0] and n_records <= capacities[1] and max_super <= capacities[2]
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
@@ -299,11 +308,18 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         elif rc != 0:
             _lib.check(rc, "sc_isect_bin_sort")
     n_isects, _, n_records, max_super = read_meta()     # the one host wait of a frame; GPU already has work
-    if rc is None or n_isects > pred[0] or n_records > pred[1] or max_super > pred[2]:
+    # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
+    # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
+    if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):
+        if rc is not None:     # a predicted launch was enqueued and (by the device's own check) did nothing:
+            # belt and braces, the cursors are re-zeroed before the exact-size launch all the same
+            _lib.check(lib.sc_isect_bin_reset_cursors(_p(ws0), C * N, C, int(tile_width), int(tile_height), st),
+                       "sc_isect_bin_reset_cursors")
         rc, ids, fids = launch(n_isects, n_records, max_super)
         if rc == -3:
             return None
         _lib.check(rc, "sc_isect_bin_sort")
+    _BIN_LAST_META[key] = (n_isects, n_records, max_super)
     # next call: 12.5 % head-room over what this frame needed
     _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, n_records + n_records // 8 + 4096,
                             min(7168, max_super + max_super // 8 + 64))

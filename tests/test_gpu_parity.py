@@ -195,6 +195,56 @@ def test_isect_bin_falls_back_when_a_super_tile_overflows_lds(ops):
     np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, 6, 4))
 
 
+@pytest.mark.parametrize("how", ["super_just_below", "super_rounding_window", "isects_too_small", "records_too_small",
+                                 "all_too_small", "generous"])
+def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
+    """The scatter + sort are enqueued with capacities predicted from the previous frame and verified on the
+    device; a wrong prediction must end in ONE full run with exact sizes (a launch that passed the
+    device check while the host decided to retry ran the scatter twice on advanced cursors).  Every
+    mis-prediction shape, including the one inside the old 256-rounding window, must reproduce the radix
+    route bit for bit."""
+    from street_crafter_amd import rendering
+    cam = make_camera(640, 416, 700.0, 700.0)
+    sc = make_scene(60_000, seed=77, z_range=(1.0, 30.0), scale_range=(0.01, 0.2))
+    with torch.no_grad():
+        r, m2, d, _, _ = ops.fully_fused_projection(sc.means.to(DEV), None, sc.quats.to(DEV), sc.scales.to(DEV),
+                                                    cam.viewmat.to(DEV)[None], cam.K.to(DEV)[None], 640, 416,
+                                                    near_plane=0.001, far_plane=1000.0)
+    tw, th = 40, 26
+    prev = rendering.set_isect_mode("radix")
+    try:
+        e_tpg, e_ids, e_f = ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)
+        e_off = ops.isect_offset_encode(e_ids, 1, tw, th)
+    finally:
+        rendering.set_isect_mode(prev)
+    key = (torch.cuda.current_device(), 1, sc.n, 16, tw, th)
+    rendering._BIN_PREDICTION.pop(key, None)
+    ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)                   # learns the true sizes
+    n_is, n_rec, max_super = rendering._BIN_LAST_META[key]
+    assert n_is == int(e_ids.numel()) and max_super > 300
+    big = 1 << 26
+    window = (max_super + 255) // 256 * 256 - 255            # smallest value that rounds up to the same multiple
+    seeds = {
+        "super_just_below": (big, big, max_super - 1),
+        # old bug: host compared with the unrounded number, device with the value rounded up to 256
+        "super_rounding_window": (big, big, min(window, max_super - 1)),
+        "isects_too_small": (n_is - 1, big, 7168),
+        "records_too_small": (big, max(1, n_rec // 2), 7168),
+        "all_too_small": (1, 1, 1),
+        "generous": (big, big, 7168),
+    }
+    pred = seeds[how]
+    if how == "super_rounding_window":
+        assert pred[2] < max_super <= (pred[2] + 255) // 256 * 256 or max_super % 256 == 1
+    for _ in range(2):                                                    # second pass: prediction learnt from the retry
+        rendering._BIN_PREDICTION[key] = pred
+        tpg, ids, fids = ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)
+        off = ops.isect_offset_encode(ids, 1, tw, th)
+        assert torch.equal(tpg, e_tpg) and torch.equal(ids, e_ids) and torch.equal(fids, e_f) and torch.equal(off, e_off)
+        pred = rendering._BIN_PREDICTION[key]
+    assert rendering._bin_launch_ran((10, 10, 10), 10, 10, 10) and not rendering._bin_launch_ran((10, 10, 10), 10, 10, 11)
+
+
 def test_radix_sort_large_stable(ops):
     """4.2 M pairs with heavy key duplication vs torch.sort(stable=True) (same device)."""
     from street_crafter_amd import _lib
