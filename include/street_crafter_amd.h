@@ -206,12 +206,18 @@ int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* 
                         int64_t n_isects, float* render_colors, float* render_alphas, void* workspace,
                         size_t ws_bytes, sc_stream_t stream);
 
-/* ---- frame export for the multi-GPU gather (no reference counterpart: the reference's visualizer
- *      does .cpu().numpy() per frame, street_gaussian/visualizers/street_gaussian_visualizer.py:82-101)
- * rgb: f32 pixels with `channel_stride` floats per pixel (>= 3; e.g. 4 for the RGB+depth image);
- * out: uint8 [n_pixels, 3] = clamp(rgb,0,1)*255 rounded half up. */
-int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8_t* out,
-                   sc_stream_t stream);
+/* ---- frame export for the multi-GPU gather: the tail of render_novel_view
+ *      (street_gaussian/models/street_gaussian_renderer.py:151-163: fg + sky * (1 - acc), clamp) and the
+ *      visualizer's uint8 conversion (street_gaussian/visualizers/street_gaussian_visualizer.py:88-101),
+ *      which the reference does with torch elementwise ops + .cpu().numpy() per frame.
+ * fg / sky: the rasterizer's raw f32 images with `*_stride` floats per pixel (>= 3; 4 for RGB+depth);
+ * acc: the foreground pass's alpha [n_pixels]; sky and acc are both given or both NULL (single pass).
+ * out u8[n_pixels,3] = q(clamp(clamp(fg,0,1) + clamp(sky,0,1) * (1 - acc), 0, 1)), with
+ * rounding 0: q(x) = (uint8)(x * 255)        -- the novel-view video frames, `(rgb * 255).astype(np.uint8)`
+ * rounding 1: q(x) = (uint8)(x * 255 + 0.5)  -- torchvision.utils.save_image PNGs.
+ * Each product / sum is rounded separately: bit-identical to the reference's torch composition. */
+int sc_frame_composite_u8(const float* fg, int fg_stride, const float* acc, const float* sky, int sky_stride,
+                          int64_t n_pixels, int rounding, uint8_t* out, sc_stream_t stream);
 
 /* unit-test hook for the backward kernel's transposing reduction (v_permlane32/16_swap + DPP):
  * in [n_waves][16][64] per-lane partial sums, out [n_waves][64]: lane l = 64-lane total of value l >> 2 */

@@ -483,3 +483,46 @@ def psnr(img1, img2):
     if mse == 0.0:
         return float("inf")
     return 20.0 * math.log10(1.0 / math.sqrt(mse))
+
+
+# --------------------------------------------------------------------------
+# render_novel_view's two-pass frame  (renderer.py:136-163, render_sky :80-93)
+# --------------------------------------------------------------------------
+def composite_sky(fg_rgb, fg_acc, sky_rgb):
+    """rgb = clamp(clamp(fg) + clamp(sky) * (1 - acc), 0, 1): each pass is clamped by render_kernel_gsplat
+    in every mode but train (renderer.py:290-291), then `rgb + rgb_sky * (1 - acc)` (:152) and the final
+    clamp (:159).  fp32, one rounding per operation.  fg_rgb / sky_rgb [...,3], fg_acc [...,1] or [...]."""
+    one, zero = F32(1.0), F32(0.0)
+    fg = np.clip(_f(fg_rgb), zero, one)
+    sky = np.clip(_f(sky_rgb), zero, one)
+    acc = _f(fg_acc)
+    if acc.ndim == fg.ndim - 1:
+        acc = acc[..., None]
+    return np.clip(fg + sky * (one - acc), zero, one).astype(np.float32)
+
+
+def quantise_u8(rgb, rounding="video"):
+    """[0,1] float image -> uint8 the way the reference's visualizer does it: "video" =
+    `(rgb * 255).astype(np.uint8)` (street_gaussian_visualizer.py:97; base_visualizer.py:37),
+    "save_image" = torchvision.utils.save_image's `mul(255).add_(0.5).clamp_(0, 255).to(uint8)`."""
+    v = _f(rgb) * F32(255.0)
+    if rounding == "save_image":
+        v = np.clip(v + F32(0.5), F32(0.0), F32(255.0))
+    elif rounding != "video":
+        raise ValueError(rounding)
+    return v.astype(np.uint8)
+
+
+def render_novel_view(fg, sky, viewmat, K, width, height, **kw):
+    """fg / sky: dicts with means, quats, scales, opacities, sh, sh_degree (sky may be None).
+    -> dict(rgb [H,W,3] composited + clamped, fg=render_frame(fg), sky=render_frame(sky) | None)."""
+    def one(s):
+        return render_frame(s["means"], s["quats"], s["scales"], s["opacities"], s["sh"], viewmat, K, width,
+                            height, s["sh_degree"], **kw)
+    rf = one(fg)
+    if sky is None:
+        rgb = np.clip(rf["render_colors"][0, ..., :3], F32(0.0), F32(1.0))
+        return dict(rgb=rgb, fg=rf, sky=None)
+    rs = one(sky)
+    rgb = composite_sky(rf["render_colors"][0, ..., :3], rf["render_alphas"][0], rs["render_colors"][0, ..., :3])
+    return dict(rgb=rgb, fg=rf, sky=rs)

@@ -69,7 +69,8 @@ SIGNATURES = {
                                    c_stream]),
     "sc_knn_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "sc_knn3_mean_dist2": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
-    "sc_frame_to_u8": (C.c_int, [c_f32p, C.c_int64, C.c_int, c_u8p, c_stream]),
+    "sc_frame_composite_u8": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int64, C.c_int, c_u8p,
+                                        c_stream]),
     "sc_test_wave_transpose_sum16": (C.c_int, [c_f32p, C.c_int, c_f32p, c_stream]),
     "sc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
 }

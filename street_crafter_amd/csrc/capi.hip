@@ -44,29 +44,46 @@ extern "C" int sc_set_option(const char* key, int value) {
 }
 
 // ---- frame export used by the multi-GPU gather (street_crafter_amd/dist.py) ---------------------
-// rgb f32 [C?,H,W,>=3] with channel stride `cstride` floats per pixel -> uint8 [H,W,3]:
-// clamp to [0,1], *255, round half up.  One pass instead of five torch elementwise kernels.
+// The tail of render_novel_view (street_gaussian_renderer.py:151-163) plus the visualizer's uint8
+// conversion, as ONE pass over the frame:
+//     rgb = clamp(clamp(fg, 0, 1) + clamp(sky, 0, 1) * (1 - acc), 0, 1)     (sky / acc optional)
+//     u8  = (uint8)(rgb * 255)          rounding 0: the video frames, (rgb * 255).astype(np.uint8)
+//                                       (street_gaussian_visualizer.py:97, base_visualizer.py:37)
+//     u8  = (uint8)(rgb * 255 + 0.5)    rounding 1: torchvision.utils.save_image's PNGs
+// fg / sky are the rasterizer's raw [H,W,C>=3] images (the per-pass clamp of renderer.py:290-291 is
+// folded in).  Every product / sum is a separately rounded fp32 op, so the result is bit-identical to
+// the torch composition the reference spells out.
 namespace {
-__global__ __launch_bounds__(256) void frame_to_u8_kernel(const float* __restrict__ src, int64_t n_pix,
-                                                          int cstride, uint8_t* __restrict__ dst) {
+__global__ __launch_bounds__(256) void frame_composite_u8_kernel(
+    const float* __restrict__ fg, int fg_stride, const float* __restrict__ acc,
+    const float* __restrict__ sky, int sky_stride, int64_t n_pix, int rounding, uint8_t* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pix) return;
-    const float* p = src + i * cstride;
+    const float* p = fg + i * fg_stride;
+    const float* q = sky ? sky + i * sky_stride : nullptr;
+    const float keep = sky ? __fsub_rn(1.0f, acc[i]) : 0.0f;
+    const float bias = rounding ? 0.5f : 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float v = fminf(fmaxf(p[c], 0.0f), 1.0f) * 255.0f + 0.5f;
-        dst[i * 3 + c] = (uint8_t)v;
+        float v = fminf(fmaxf(p[c], 0.0f), 1.0f);
+        if (sky) {
+            const float s = fminf(fmaxf(q[c], 0.0f), 1.0f);
+            v = fminf(fmaxf(__fadd_rn(v, __fmul_rn(s, keep)), 0.0f), 1.0f);
+        }
+        dst[i * 3 + c] = (uint8_t)__fadd_rn(__fmul_rn(v, 255.0f), bias);
     }
 }
 }  // namespace
 
-extern "C" int sc_frame_to_u8(const float* rgb, int64_t n_pixels, int channel_stride, uint8_t* out,
-                              sc_stream_t stream) {
-    if (n_pixels < 0 || channel_stride < 3) return SC_EINVAL;
+extern "C" int sc_frame_composite_u8(const float* fg, int fg_stride, const float* acc, const float* sky,
+                                     int sky_stride, int64_t n_pixels, int rounding, uint8_t* out,
+                                     sc_stream_t stream) {
+    if (n_pixels < 0 || fg_stride < 3 || (sky && sky_stride < 3) || (rounding != 0 && rounding != 1)) return SC_EINVAL;
+    if ((sky != nullptr) != (acc != nullptr)) return SC_EINVAL;
     if (n_pixels == 0) return SC_OK;
-    if (!rgb || !out) return SC_EINVAL;
-    hipLaunchKernelGGL(frame_to_u8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, sc_s(stream),
-                       rgb, n_pixels, channel_stride, out);
+    if (!fg || !out) return SC_EINVAL;
+    hipLaunchKernelGGL(frame_composite_u8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
+                       sc_s(stream), fg, fg_stride, acc, sky, sky_stride, n_pixels, rounding, out);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

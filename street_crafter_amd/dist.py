@@ -1,19 +1,34 @@
-"""One-frame-per-GPU sharding of the novel-view loop with a gather of rendered frames.
+"""One-frame-per-GPU sharding of the novel-view loop with a batched gather of rendered frames.
 
 The reference renders frames in a plain sequential loop (render.py:64-70: no cross-frame state,
 model read-only under no_grad), single process, single GPU; it has no collective to mirror
 (SURVEY.md 2.2, 8e).  Here: one process per GPU (torch.distributed, backend "nccl" = RCCL over
 xGMI on ROCm; "gloo" on CPU for tests), frame f is rendered by rank f % world, and finished
-frames are gathered to rank 0 as uint8 [H,W,3] (7.4 MB at 1920x1280 -- tiny against 7 x 153 GB/s
-of xGMI into the root), asynchronously, so the next frame's raster overlaps the transfer.
-No data-path collective exists besides this gather: the shards are independent (weak scaling).
+frames travel to rank 0 as uint8 [H,W,3] (7.4 MB at 1920x1280), `batch` frames per collective
+(one `gather` of uint8[K,H,W,3] instead of K: the root otherwise enqueues world-1 receives every
+half millisecond), asynchronously, from a ring of staging buffers, so rendering never waits for
+a transfer.  No data-path collective exists besides this gather: the shards are independent
+(weak scaling).  `launch_ranks` starts the ranks of a single-node job from a parent process that
+never touches the GPU.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional
+import os
+import socket
+import subprocess
+import sys
+import time
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+# uint8 quantisation of a [0,1] image, as the reference's visualizer does it:
+#   "video"      (x * 255).astype(np.uint8): the frames render_novel_view collects for the video
+#                (street_gaussian_visualizer.py:97, base_visualizer.py:37; render.py:48-49 turns
+#                save_video on and save_image off for mode=novel_view) -- truncation
+#   "save_image" torchvision.utils.save_image's PNGs (street_gaussian_visualizer.py:92): x * 255 + 0.5
+ROUNDING = {"video": 0, "save_image": 1}
 
 
 def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
@@ -21,87 +36,286 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_frames, world))
 
 
-def to_uint8_frame(rgb_chw: torch.Tensor) -> torch.Tensor:
-    """[3,H,W] float -> [H,W,3] uint8 = clamp(.,0,1)*255 rounded half up (what the reference's
-    visualizer writes to disk).  On a HIP device this is ONE fused kernel (sc_frame_to_u8) when
-    the tensor is the permuted view of an [H,W,C>=3] image, as the renderer returns it."""
+def _hwc_view(x: torch.Tensor):
+    """[3,H,W] tensor that is a permuted view of an [H,W,C>=3] image -> (that [H,W,3] view, pixel stride)
+    or None."""
+    if x.dim() != 3 or x.shape[0] != 3:
+        return None
+    hwc = x.permute(1, 2, 0)
+    H, W = hwc.shape[0], hwc.shape[1]
+    if hwc.stride(2) == 1 and hwc.stride(1) >= 3 and hwc.stride(0) == W * hwc.stride(1):
+        return hwc, hwc.stride(1)
+    return None
+
+
+def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
+                   sky_rgb_chw: Optional[torch.Tensor] = None, rounding: str = "video",
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[3,H,W] float -> [H,W,3] uint8, the tail of render_novel_view + the visualizer's conversion:
+    `clamp(clamp(rgb) + clamp(sky) * (1 - acc), 0, 1)` (street_gaussian_renderer.py:151-163; sky / acc
+    optional: both or neither), then `rounding` "video" (truncate, default: what mode=novel_view keeps)
+    or "save_image" (+0.5).  On a HIP device this is ONE fused kernel (sc_frame_composite_u8) when the
+    images are permuted views of the rasterizer's [H,W,C>=3] outputs, as the renderer returns them.
+    `out`: optional preallocated uint8 [H,W,3] (e.g. a slot of a gather batch)."""
+    if rounding not in ROUNDING:
+        raise ValueError(f"rounding must be one of {sorted(ROUNDING)}, got {rounding!r}")
+    if (acc is None) != (sky_rgb_chw is None):
+        raise ValueError("acc and sky_rgb_chw go together (two-pass frame) or are both None")
     x = rgb_chw.detach()
-    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] == 3:
-        hwc = x.permute(1, 2, 0)                      # [H,W,3] view
-        H, W = hwc.shape[0], hwc.shape[1]
-        if hwc.stride(2) == 1 and hwc.stride(1) >= 3 and hwc.stride(0) == W * hwc.stride(1):
+    H, W = x.shape[1], x.shape[2]
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+    else:
+        assert out.shape == (H, W, 3) and out.dtype == torch.uint8 and out.is_contiguous() and out.device == x.device
+    if x.is_cuda and x.dtype == torch.float32:
+        fg = _hwc_view(x)
+        sky = _hwc_view(sky_rgb_chw.detach()) if sky_rgb_chw is not None else None
+        a = acc.detach().reshape(H, W) if acc is not None else None
+        if fg is not None and (sky_rgb_chw is None or (sky is not None and a.is_contiguous()
+                                                      and a.dtype == torch.float32)):
             from . import _lib
-            out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
-            _lib.check(_lib.load().sc_frame_to_u8(hwc.data_ptr(), H * W, hwc.stride(1), out.data_ptr(),
-                                                  torch.cuda.current_stream(x.device).cuda_stream),
-                       "sc_frame_to_u8")
+            _lib.check(_lib.load().sc_frame_composite_u8(
+                fg[0].data_ptr(), fg[1], None if a is None else a.data_ptr(),
+                None if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1], H * W,
+                ROUNDING[rounding], out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                "sc_frame_composite_u8")
             return out
-    return (x.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).contiguous()
+    v = x.float().clamp(0.0, 1.0)
+    if sky_rgb_chw is not None:
+        v = (v + sky_rgb_chw.detach().float().clamp(0.0, 1.0) * (1.0 - acc.detach().float().reshape(1, H, W))).clamp(0.0, 1.0)
+    v = v * 255.0
+    if ROUNDING[rounding]:
+        v = v + 0.5
+    out.copy_(v.to(torch.uint8).permute(1, 2, 0))
+    return out
 
 
 class FrameGatherer:
-    """Gathers one frame per rank per round to `dst`.  `submit()` starts an async gather and
-    returns immediately; `drain()` waits for everything outstanding and returns, on dst, the
-    frames in global frame order."""
+    """Gathers rendered frames to `dst`, `batch` rounds per collective.
 
-    def __init__(self, dst: int = 0, group=None):
-        self.dst = dst
-        self.group = group
+    Round r = one frame from every rank (global frame index r * world + rank).  `slot(r)` hands out the
+    uint8 [H,W,3] view the renderer writes round r's frame into (no copy); `submit(r)` marks it written
+    (ordered after everything enqueued on the CURRENT stream) and, when its batch is complete, starts ONE
+    async `gather` of uint8 [batch,H,W,3] per rank.  Staging buffers form a ring of `ring` batches, so
+    rendering only waits for a gather when it is `ring` batches behind.  `drain()` flushes a partial
+    batch, waits for everything and returns, on dst, the frames in global frame order.
+
+    Frames may be produced on several HIP streams (frames in flight): the gather of a batch waits for
+    the recorded event of each of its frames."""
+
+    def __init__(self, frame_shape: Sequence[int], device, dst: int = 0, group=None, batch: int = 8,
+                 ring: int = 3, keep: bool = True):
+        self.dst, self.group = dst, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._pending = []          # (work, round_index, gather_list | None, frame)
-        self._done = {}             # global frame index -> tensor (dst only)
+        self.batch, self.ring = max(1, int(batch)), max(2, int(ring))
+        self.shape = tuple(int(v) for v in frame_shape)
+        self.device = torch.device(device)
+        self.keep = keep
+        # world 1: nothing to gather, frames are handed out as fresh tensors and kept as they are
+        self._staging = [] if self.world == 1 else [
+            torch.empty((self.batch, *self.shape), dtype=torch.uint8, device=self.device) for _ in range(self.ring)]
+        self._single: Dict[int, torch.Tensor] = {}
+        self._busy: List[Optional[object]] = [None] * self.ring    # outstanding work per ring entry
+        self._events: Dict[int, object] = {}                      # round -> event on its stream (HIP only)
+        self._written: Dict[int, int] = {}                        # batch index -> rounds written
+        self._pending = []                                        # (work, batch index, n rounds, recv list)
+        self._done: Dict[int, torch.Tensor] = {}                  # global frame -> tensor (dst only)
+        self.stats = {"gathers": 0, "bytes_per_gather": 0, "host_s_in_gather_calls": 0.0,
+                      "host_s_waiting_for_ring": 0.0}
 
-    def submit(self, round_index: int, frame_u8: torch.Tensor):
+    def slot(self, round_index: int) -> torch.Tensor:
         if self.world == 1:
-            self._done[round_index] = frame_u8
-            return
-        glist = None
-        if self.rank == self.dst:
-            glist = [torch.empty_like(frame_u8) for _ in range(self.world)]
-        work = dist.gather(frame_u8, gather_list=glist, dst=self.dst, group=self.group, async_op=True)
-        self._pending.append((work, round_index, glist, frame_u8))
+            t = self._single.get(int(round_index))
+            if t is None:
+                t = self._single[int(round_index)] = torch.empty(self.shape, dtype=torch.uint8, device=self.device)
+            return t
+        b, j = divmod(int(round_index), self.batch)
+        e = b % self.ring
+        w = self._busy[e]
+        if w is not None:
+            # ring wrapped: the gather that last read this buffer must be done before the CURRENT stream
+            # writes into it (every slot of the batch waits: its frames may be on different streams).
+            # nccl: orders the stream, does not block the host; gloo: blocks until the transfer is done.
+            t0 = time.perf_counter()
+            w.wait()
+            self.stats["host_s_waiting_for_ring"] += time.perf_counter() - t0
+        return self._staging[e][j]
 
-    def drain(self):
-        for work, r, glist, _ in self._pending:
+    def submit(self, round_index: int, frame_u8: Optional[torch.Tensor] = None):
+        """frame_u8: given only when the frame was NOT written into slot(round_index) (it is copied in)."""
+        r = int(round_index)
+        if self.world == 1:
+            t = self._single.pop(r, None) if frame_u8 is None else frame_u8
+            self._single.pop(r, None)
+            if t is None:
+                raise RuntimeError(f"round {r}: no frame was written (call slot({r}) or pass the frame)")
+            if self.keep:
+                self._done[r] = t
+            return
+        if frame_u8 is not None:
+            s = self.slot(r)
+            if frame_u8.data_ptr() != s.data_ptr():
+                s.copy_(frame_u8)
+        b = r // self.batch
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._events[r] = ev
+        self._written[b] = self._written.get(b, 0) + 1
+        if self._written[b] == self.batch:
+            self._flush(b, self.batch)
+
+    def _flush(self, b: int, n_rounds: int):
+        e = b % self.ring
+        send = self._staging[e][:n_rounds]
+        del self._written[b]
+        t0 = time.perf_counter()
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            for j in range(n_rounds):
+                ev = self._events.pop(b * self.batch + j, None)
+                if ev is not None:
+                    cur.wait_event(ev)
+        recv = None
+        if self.rank == self.dst:
+            recv = [torch.empty_like(send) for _ in range(self.world)]
+        work = dist.gather(send, gather_list=recv, dst=self.dst, group=self.group, async_op=True)
+        self._busy[e] = work
+        self._pending.append((work, b, n_rounds, recv))
+        self.stats["gathers"] += 1
+        self.stats["bytes_per_gather"] = send.numel() * (self.world - 1)
+        self.stats["host_s_in_gather_calls"] += time.perf_counter() - t0
+
+    def drain(self) -> List[torch.Tensor]:
+        for b in sorted(self._written):
+            self._flush(b, self._written[b])
+        for work, b, n_rounds, recv in self._pending:
             work.wait()
-            if glist is not None:
-                for k, f in enumerate(glist):
-                    self._done[r * self.world + k] = f
+            if recv is not None and self.keep:
+                for k, batch_k in enumerate(recv):
+                    for j in range(n_rounds):
+                        self._done[(b * self.batch + j) * self.world + k] = batch_k[j]
         self._pending.clear()
+        self._busy = [None] * self.ring
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
         if self.rank != self.dst:
             return []
         return [self._done[k] for k in sorted(self._done)]
 
+    def reset(self):
+        self._done.clear()
 
-def render_sharded(n_frames: int, render_frame: Callable[[int], torch.Tensor], dst: int = 0,
-                   group=None, frames_in_flight: int = 1) -> Optional[List[torch.Tensor]]:
+
+def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,
+                   group=None, frames_in_flight: int = 1, batch: int = 8) -> Optional[List[torch.Tensor]]:
     """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
-    (None elsewhere).  n_frames must be a multiple of the world size (every round is a full
-    gather); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device.
+    (None elsewhere).  n_frames must be a multiple of the world size (every round is one frame per
+    rank); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device (if it accepts a
+    keyword `out`, it is handed the staging slot to write into and the copy is skipped).
 
     frames_in_flight > 1 (HIP devices only): this rank's frames alternate over that many HIP streams, so
     the latency-bound intersection kernels of one frame run under the rasterizer of another (+20 % frames/s
-    with 2 on S-1M, identical images; bench.py `two_frames_in_flight`).  Frames are independent, every
-    operator launches on torch's current stream, and the gather of a frame is enqueued on its stream."""
+    with 2 on S-1M, identical images).  Frames are independent, every operator launches on torch's current
+    stream, and the gather of a batch waits for the events of its frames."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if n_frames % world:
         raise ValueError(f"n_frames={n_frames} must be a multiple of world size {world}")
-    g = FrameGatherer(dst, group)
+    mine = frames_for_rank(n_frames, rank, world)
+    if not mine:
+        return [] if rank == dst else None
+    import inspect
+    takes_out = "out" in inspect.signature(render_frame).parameters
+    g = None
     streams = None
-    if frames_in_flight > 1 and torch.cuda.is_available():
-        streams = [torch.cuda.Stream() for _ in range(int(frames_in_flight))]
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-    for r, f in enumerate(frames_for_rank(n_frames, rank, world)):
-        if streams is None:
-            g.submit(r, render_frame(f))
-        else:
-            with torch.cuda.stream(streams[r % len(streams)]):
+    for r, f in enumerate(mine):
+        ctx = None
+        if g is not None and streams is not None:
+            ctx = torch.cuda.stream(streams[r % len(streams)])
+            ctx.__enter__()
+        try:
+            if g is None:                 # the first frame tells the frame shape / device
+                first = render_frame(f)
+                g = FrameGatherer(first.shape, first.device, dst, group, batch=min(batch, len(mine)))
+                if frames_in_flight > 1 and first.is_cuda:
+                    streams = [torch.cuda.Stream(device=first.device) for _ in range(int(frames_in_flight))]
+                    for st in streams:
+                        st.wait_stream(torch.cuda.current_stream(first.device))
+                g.submit(r, first)
+            elif takes_out:
+                render_frame(f, out=g.slot(r))
+                g.submit(r)
+            else:
                 g.submit(r, render_frame(f))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
     if streams is not None:
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
     frames = g.drain()
     return frames if rank == dst else None
+
+
+# ---- single-node launcher -----------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks(argv: Sequence[str], world: int, env: Optional[Dict[str, str]] = None,
+                 timeout: Optional[float] = None) -> int:
+    """Starts `world` copies of `argv` (one per rank: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set, rendezvous on 127.0.0.1) as child processes, waits for them, and returns the worst
+    exit code.  If a rank fails, the others are terminated (the exact PIDs started here).  The CALLER
+    must not have initialised the GPU: children are started with subprocess (fork + exec of a fresh
+    interpreter), never by exec-ing over a process that holds a HIP context."""
+    base = dict(os.environ if env is None else env)
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("MASTER_PORT", str(free_port()))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base["WORLD_SIZE"] = str(int(world))
+    procs = []
+    for r in range(int(world)):
+        e = dict(base)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen(list(argv), env=e))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    worst = 0
+    alive = set(range(len(procs)))
+    while alive:
+        for i in sorted(alive):
+            rc = procs[i].poll()
+            if rc is None:
+                continue
+            alive.discard(i)
+            if rc != 0:
+                worst = worst or rc
+                for j in alive:                # one rank failed: the job cannot finish
+                    procs[j].terminate()
+        if deadline is not None and time.monotonic() > deadline:
+            for j in alive:
+                procs[j].terminate()
+            worst = worst or 124
+            deadline = None
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    if worst < 0:
+        worst = 128 - worst
+    return worst
+
+
+def visible_gpus() -> int:
+    """Number of HIP devices WITHOUT creating a context (safe in a launcher parent)."""
+    return int(torch.cuda.device_count())
+
+
+if __name__ == "__main__":          # python -m street_crafter_amd.dist N prog args...
+    sys.exit(launch_ranks(sys.argv[2:], int(sys.argv[1])))

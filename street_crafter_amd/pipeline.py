@@ -104,3 +104,49 @@ def algorithmic_bytes(n_gauss: int, n_isects: int, width: int, height: int, tile
     tiles = math.ceil(width / tile_size) * math.ceil(height / tile_size)
     per_gauss = 72 + (12 + 12 * sh_bases + 1 + 12) + 52
     return per_gauss * n_gauss + 88 * n_isects + 24 * width * height + 4 * tiles
+
+
+def render_novel_view(fg_scene: Scene, sky_scene, camera: Camera, **kw) -> Dict[str, torch.Tensor]:
+    """StreetGaussianRenderer.render_novel_view (street_gaussian_renderer.py:136-163) as the reference
+    spells it: the foreground pass over every sub-model but the sky (`render_kernel`, :148), then -- when
+    the scene has a sky sub-model (`pc.include_sky`, 5 of the 7 shipped configs) -- a second pass over the
+    sky Gaussians alone (`render_sky`, :80-93) and `rgb = rgb + rgb_sky * (1 - acc)` (:152), clamp (:159).
+    Both passes go through the drop-in operators exactly like `render_gaussians`; the composite is the
+    reference's torch expression.  `sky_scene=None`: single pass (include_sky False)."""
+    result = render_gaussians(fg_scene, camera, **kw)
+    if sky_scene is not None:
+        result_sky = render_gaussians(sky_scene, camera, **kw)
+        result["rgb"] = result["rgb"] + result_sky["rgb"] * (1 - result["acc"])
+        result["_sky"] = result_sky
+    result["rgb"] = torch.clamp(result["rgb"], 0.0, 1.0)
+    return result
+
+
+@torch.no_grad()
+def render_novel_view_u8(fg_scene: Scene, sky_scene, camera: Camera, rounding: str = "video", out=None,
+                         fused: bool = True) -> torch.Tensor:
+    """The same frame as `to_uint8_frame(render_novel_view(...)["rgb"])`, bit for bit, as the sharded
+    novel-view loop produces it: each pass is ONE call of gsplat's `rasterization()` (fused forward,
+    SURVEY 8f-2) and composite + clamp + uint8 conversion are ONE kernel (sc_frame_composite_u8) instead
+    of seven torch elementwise passes over the frame.  -> uint8 [H,W,3]."""
+    from gsplat.rendering import rasterization
+    from .dist import to_uint8_frame
+
+    def one_pass(sc):
+        if not fused:
+            o = render_gaussians(sc, camera, return_intermediates=True)
+            return o["_render_colors"], o["_render_alphas"]
+        rc, ra, _ = rasterization(sc.means, sc.quats, sc.scales, sc.opacities.reshape(-1), sc.sh,
+                                  camera.viewmat[None], camera.K[None], camera.width, camera.height,
+                                  near_plane=camera.znear, far_plane=camera.zfar, sh_degree=sc.sh_degree,
+                                  render_mode="RGB+ED", rasterize_mode="antialiased",
+                                  camera_centers_=camera.camera_center[None])
+        return rc, ra
+
+    rc, ra = one_pass(fg_scene)
+    rgb = rc[0, ..., :3].permute(2, 0, 1)
+    if sky_scene is None:
+        return to_uint8_frame(rgb, rounding=rounding, out=out)
+    rc_s, _ = one_pass(sky_scene)
+    return to_uint8_frame(rgb, acc=ra[0, ..., 0], sky_rgb_chw=rc_s[0, ..., :3].permute(2, 0, 1),
+                          rounding=rounding, out=out)
