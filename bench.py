@@ -7,9 +7,15 @@
 
 A "step" = every rank renders ONE frame of the synthetic S-1M scene (1 000 000 Gaussians,
 1920x1280, SURVEY.md 8d / BASELINE.md 2) through the drop-in gsplat operators (the caller's
-sequence of street_gaussian_renderer.py:186-302, forward only) with a per-frame camera, and the
-finished uint8 frames are gathered to rank 0 (RCCL).  Scene tensors are resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line.
+sequence of street_gaussian_renderer.py:186-302, forward only) with a per-frame camera and turns it
+into the uint8 frame the novel-view loop keeps; finished frames are gathered to rank 0 (RCCL), K
+frames per collective.  Scene tensors are resident in HBM before the timed region.  Each rank keeps
+`--frames-in-flight` (default 2) independent frames in flight on as many HIP streams; every 8th
+timed frame is a PROBE frame rendered alone (all streams drained) with HIP events around every
+operator, which is where `roofline` and `stage_ms` come from.  Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the
+GPU) starts the N ranks itself and forwards rank 0's line.
 """
 from __future__ import annotations
 
@@ -25,9 +31,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12   # B/s, MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+METRIC = "frames/sec @1M Gaussians 1920x1280 + PSNR vs ref; 1/2/4/8 MI355X"
+# kernel launched by each operator of the caller's sequence (rocprofv3 names, profiles/)
+OPERATOR_KERNEL = {
+    "projection": "projection_fwd_kernel",
+    "isect_tiles": "bin_count + center_scatter + bin_scatter_flat + super_sort (4 kernels)",
+    "isect_offset_encode": "(none: cached bucket scan)",
+    "spherical_harmonics": "sh_fwd_kernel",
+    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false>",
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -36,18 +51,23 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--sh-degree", type=int, default=1)
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="independent frames each rank keeps in flight (one HIP stream each)")
+    ap.add_argument("--gather-batch", type=int, default=8, help="frames per gather collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
     ap.add_argument("--raster-variant", type=int, default=None)
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="skip the secondary measurement with two frames in flight on two HIP streams")
-    ap.add_argument("--no-fused", action="store_true",
-                    help="skip the secondary fused rasterization() measurement (keeps profiles of the headline clean)")
-    ap.add_argument("--no-train", action="store_true", help="skip the secondary fwd+bwd (training-step) measurement")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip every secondary measurement (keeps rocprof profiles of the headline clean)")
+    ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: single_stream,fused,"
+                                               "two_pass,street,train")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
-    return ap.parse_args()
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="launcher / sharding / gather / JSON plumbing on CPU tensors over gloo with a stand-in "
+                         "frame source (no renderer, no GPU): what tests/test_dist_cpu.py drives")
+    return ap.parse_args(argv)
 
 
 def frame_camera(f, width, height):
@@ -69,23 +89,49 @@ def stage_algorithmic_bytes(stage, N, I, P, T, K):
     }[stage]
 
 
-def cpu_baseline(width, height, hip_frame_fn):
-    """Oracle (numpy, 1 thread) on S-100k at full resolution: one frame, ~10-30 s of CPU work."""
+def percentiles(values):
+    v = sorted(values)
+    if not v:
+        return None
+    pick = lambda q: v[min(len(v) - 1, int(round(q * (len(v) - 1))))]
+    return {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9), "samples": len(v)}
+
+
+def host_threads(cap=32):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(scene, cam, W, H, hip_frame_fn, budget_s=30.0):
+    """The C/OpenMP restatement of the oracle (oracle/gsplat_oracle_c.c, kind "port") on frame 0 of the SAME
+    workload (all N Gaussians, full resolution): 1 warm-up + up to 3 timed frames within `budget_s`, on the
+    host threads stated in `cores`.  The warm-up frame doubles as the parity reference for the HIP frame."""
     import numpy as np
-    from oracle import gsplat_oracle as O        # checker / baseline only
-    from street_crafter_amd.scenes import make_camera, make_scene
-    sc = make_scene(100_000)
-    cam = make_camera(width, height, 2050.0 * width / 1920.0, 2050.0 * width / 1920.0)
+    from oracle import gsplat_oracle as O          # checker / baseline only
+    from oracle import gsplat_oracle_c as OC
+    cores = host_threads()
+    OC.set_num_threads(cores)
+    args = (scene.means.cpu().numpy(), scene.quats.cpu().numpy(), scene.scales.cpu().numpy(),
+            scene.opacities.cpu().numpy(), scene.sh.cpu().numpy(), cam.viewmat.cpu().numpy(), cam.K.cpu().numpy(),
+            W, H, scene.sh_degree)
+    kw = dict(near_plane=cam.znear, far_plane=cam.zfar)
     t0 = time.perf_counter()
-    exp = O.render_frame(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(),
-                         sc.sh.numpy(), cam.viewmat.numpy(), cam.K.numpy(), width, height, sc.sh_degree,
-                         near_plane=cam.znear, far_plane=cam.zfar, return_unstable=True)
-    dt = time.perf_counter() - t0
-    got = hip_frame_fn(sc, cam)
+    exp = OC.render_frame(*args, return_unstable=True, **kw)
+    t_warm = time.perf_counter() - t0
+    n_timed = int(max(1, min(3, (budget_s - t_warm) // max(t_warm, 1e-3))))
+    times = []
+    for _ in range(n_timed):
+        t0 = time.perf_counter()
+        OC.render_frame(*args, **kw)
+        times.append(time.perf_counter() - t0)
+    got = hip_frame_fn()
     ref_rgb = np.clip(exp["render_colors"][0, ..., :3], 0.0, 1.0)
     err = np.abs(got["rgb"] - ref_rgb).max(axis=-1)
-    # pixels where some alpha / transmittance sits within 2e-5 (relative) of a hard threshold can
-    # legitimately flip on a 1-ulp exp difference (oracle flags them); reported separately
+    # pixels where some alpha / transmittance sits within 2e-5 (relative) of a hard threshold can legitimately
+    # flip on a 1-ulp exp difference (the oracle flags them); all-pixel figures are reported beside the stable ones
     stable = ~exp["unstable"][0]
     parity = {
         "psnr_db_vs_oracle": O.psnr(got["rgb"], ref_rgb),
@@ -93,273 +139,421 @@ def cpu_baseline(width, height, hip_frame_fn):
         "max_abs_rgb_all_pixels": float(err.max()),
         "threshold_unstable_pixels": int((~stable).sum()),
         "pixels_over_1e-4": int((err > 1e-4).sum()),
+        "pixels_over_1e-4_among_stable": int((err[stable] > 1e-4).sum()),
         "n_pixels": int(err.size),
         "isect_ids_and_flatten_ids_bit_exact": bool(np.array_equal(got["isect_ids"], exp["isect_ids"]) and
                                                     np.array_equal(got["flatten_ids"], exp["flatten_ids"])),
+        "radii_bit_exact": bool(np.array_equal(got["radii"], exp["radii"])),
+        "oracle": "oracle/gsplat_oracle_c.c (pinned bit-for-bit to oracle/gsplat_oracle.py on ints and "
+                  "projection / SH floats by tests/test_oracle_cpu.py)",
     }
-    return dt, int(exp["isect_ids"].shape[0]), parity
+    med = sorted(times)[len(times) // 2]
+    base = {"value": 1.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/gsplat_oracle_c.c (C + OpenMP, {cores} threads) on frame 0 of the SAME workload "
+                      f"({scene.n} Gaussians, {W}x{H}, I={int(exp['isect_ids'].shape[0])}): 1 warm-up "
+                      f"({t_warm:.2f} s) + {n_timed} timed frames, value = 1 / median ({med:.2f} s)",
+            "frame_seconds": times, "host_cpus": os.cpu_count()}
+    return base, parity
+
+
+# ---------------------------------------------------------------------------------------------
+def launch_self(args) -> int:
+    """--gpus N > 1 without a launcher: start the N ranks from here.  This parent never initialises the
+    GPU (device_count() does not create a context on this image) and never exec()s: children are fresh
+    interpreters; rank 0's JSON line goes straight to the inherited stdout."""
+    from street_crafter_amd.dist import launch_ranks, visible_gpus
+    if not args.selftest_cpu:
+        have = visible_gpus()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but this machine exposes {have} GPU(s); "
+                  f"run with --gpus {max(have, 1)} (the 8-GPU curve comes from the driver's 8-GPU node)",
+                  file=sys.stderr)
+            return 2
+    return launch_ranks([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], args.gpus)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_self(args))
+    run_rank(args)
+
+
+def run_rank(args):
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+              f"(or without a launcher: bench.py starts its own ranks)", file=sys.stderr)
+        sys.exit(2)
+    selftest = args.selftest_cpu
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (HIP); there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    from street_crafter_amd import _lib, rendering
-    from street_crafter_amd.dist import FrameGatherer, to_uint8_frame
-    from street_crafter_amd.pipeline import algorithmic_bytes, render_gaussians
-    from street_crafter_amd.scenes import make_scene
-    _lib.load()
-    if args.isect_mode:
-        rendering.set_isect_mode(args.isect_mode)
-    if args.raster_variant is not None:
-        _lib.set_option("raster_fwd", args.raster_variant)
-
-    W, H = args.width, args.height
-    if args.scene_ply:
-        # a scene in the reference's point_cloud.ply layout (street_crafter_amd/scene_io.py); actors, if
-        # any, are placed with identity poses.  Not the headline workload: the metric string stays S-1M's.
-        from street_crafter_amd import scene_io
-        models = scene_io.read_ply(args.scene_ply)
-        ident = (torch.tensor([1.0, 0.0, 0.0, 0.0]), torch.zeros(3))
-        composed = scene_io.compose_scene(models, {n: ident for n in models if n not in ("background", "sky")})
-        scene = composed.scene.to(dev)
-        args.n_gauss, args.sh_degree = scene.n, scene.sh_degree
+    if selftest:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
-        scene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)     # resident before timing
-    K = (args.sh_degree + 1) ** 2
+        if not torch.cuda.is_available():
+            print("bench.py needs a GPU (HIP); there is no CPU path", file=sys.stderr)
+            sys.exit(2)
+        if local_rank >= torch.cuda.device_count():
+            print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, "
+                  f"{torch.cuda.device_count()} visible)", file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+
+    from street_crafter_amd.dist import FrameGatherer, to_uint8_frame
+    W, H = args.width, args.height
     total_steps = args.warmup + args.steps
-    cams = [frame_camera(rank + s * world, W, H).to(dev) for s in range(total_steps)]
-    gatherer = FrameGatherer(dst=0)
-    events = {}
-    n_isects = []
-    frame_events = []
+    n_streams = 1 if selftest else max(1, args.frames_in_flight)
+    skip = set(x for x in args.skip.split(",") if x)
+    if args.headline_only:
+        skip |= {"single_stream", "fused", "two_pass", "street", "train"}
 
-    def step(s, timed):
-        # per-operator HIP events cost ~200 us of host time per frame (10 event pairs), so they are
-        # recorded on every 8th timed step only; the kernels and the stream are the same either way
-        probe = timed and ((s - args.warmup) % 8 == 0)
-        with torch.no_grad():
-            if probe:
-                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                f0.record()
-            out = render_gaussians(scene, cams[s], stage_events=events if probe else None,
-                                   return_intermediates=probe)
-            if probe:
-                n_isects.append(int(out["_isect_ids"].numel()))
-            gatherer.submit(s, to_uint8_frame(out["rgb"]))
-            if probe:
-                f1.record()
-                frame_events.append((f0, f1))
+    if selftest:
+        W, H = 64, 48
+        scene = cams = None
+        K = 4
 
-    for s in range(args.warmup):
-        step(s, False)
-    gatherer.drain()
-    gatherer._done.clear()
+        def render_into(s, out, events=None, intermediates=False):
+            out.fill_((7 * (rank + s * world)) % 251)       # stand-in frame: a function of the GLOBAL frame index
+            return None
+    else:
+        from street_crafter_amd import _lib, rendering
+        from street_crafter_amd.pipeline import algorithmic_bytes, render_gaussians
+        from street_crafter_amd.scenes import make_scene
+        _lib.load()
+        if args.isect_mode:
+            rendering.set_isect_mode(args.isect_mode)
+        if args.raster_variant is not None:
+            _lib.set_option("raster_fwd", args.raster_variant)
+        if args.scene_ply:
+            # a scene in the reference's point_cloud.ply layout (street_crafter_amd/scene_io.py); actors, if
+            # any, are placed with identity poses.  Not the headline workload: the metric string stays S-1M's.
+            from street_crafter_amd import scene_io
+            models = scene_io.read_ply(args.scene_ply)
+            ident = (torch.tensor([1.0, 0.0, 0.0, 0.0]), torch.zeros(3))
+            composed = scene_io.compose_scene(models, {n: ident for n in models if n not in ("background", "sky")})
+            scene = composed.scene.to(dev)
+            args.n_gauss, args.sh_degree = scene.n, scene.sh_degree
+        else:
+            scene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)     # resident before timing
+        K = (args.sh_degree + 1) ** 2
+        cams = [frame_camera(rank + s * world, W, H).to(dev) for s in range(total_steps)]
 
+        def render_into(s, out, events=None, intermediates=False):
+            with torch.no_grad():
+                o = render_gaussians(scene, cams[s], stage_events=events, return_intermediates=intermediates)
+                to_uint8_frame(o["rgb"], out=out)
+            return o
+
+    gatherer = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if (not selftest and n_streams > 1) else None
+    events, n_isects, frame_ev, probe_ev = {}, [], [], []
+
+    def sync_streams():
+        if not selftest:
+            torch.cuda.synchronize(dev)
+
+    def run_steps(first, last, timed, g, step_fn, n_str=n_streams, probes=True):
+        """steps [first, last): frame s on stream s % n_str; every 8th timed step is a probe frame, rendered
+        ALONE (streams drained before and after) with per-operator HIP events."""
+        strs = streams[:n_str] if (streams is not None and n_str > 1) else None
+        for s in range(first, last):
+            r = s - first          # round number of this run (the gatherer is reset between runs)
+            probe = probes and timed and ((s - first) % 8 == 0) and not selftest
+            if probe and strs is not None:
+                sync_streams()
+            ctx = torch.cuda.stream(strs[s % n_str]) if (strs is not None and not probe) else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                ev = None
+                if timed and not selftest:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                o = step_fn(s, g.slot(r), events if probe else None, probe)
+                if ev is not None:
+                    ev[1].record()
+                    (probe_ev if probe else frame_ev).append(ev)
+                if probe and o is not None:
+                    n_isects.append(int(o["_isect_ids"].numel()))
+                g.submit(r)
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+            if probe and strs is not None:
+                sync_streams()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def timed_run(step_fn, g, n_str=n_streams, probes=True):
+        run_steps(0, args.warmup, False, g, step_fn, n_str, probes)
+        g.drain()
+        g.reset()
+        barrier()
+        sync_streams()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, total_steps, True, g, step_fn, n_str, probes)
+        t_submitted = time.perf_counter()
+        frames = g.drain()
+        sync_streams()
+        barrier()
+        sync_streams()
+        t1 = time.perf_counter()
+        return t1 - t0, t1 - t_submitted, frames
+
+    elapsed_local, drain_s, frames = timed_run(render_into, gatherer)
+    elapsed = elapsed_local
+    per_rank_fps = [args.steps / elapsed_local]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(args.warmup, total_steps):
-        step(s, True)
-    frames = gatherer.drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank_fps = [args.steps / float(x.item()) for x in allt]
+        elapsed = max(float(x.item()) for x in allt)
     if rank == 0:
         assert len(frames) == args.steps * world, (len(frames), args.steps, world)
+        if selftest:
+            for k, f in enumerate(frames):
+                r_, w_ = divmod(k, world)
+                expect = (7 * (w_ + (r_ + args.warmup) * world)) % 251
+                assert int(f[0, 0, 0]) == expect and int(f.min()) == int(f.max()), (k, int(f[0, 0, 0]), expect)
 
-    # SURVEY 8f-2 (secondary, N = 1 only): the same frames through gsplat's one-call `rasterization()`,
-    # whose forward is fused (projection + SH + glue in one kernel, depth normalisation in the raster
-    # epilogue).  `value` above stays the reference caller's own operator sequence.
-    fused_line = None
-    if world == 1 and not args.no_fused:
+    line = None
+    if rank == 0:
+        fps = args.steps * world / elapsed
+        line = {
+            "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "per_rank_frames_per_s": per_rank_fps,
+            "gather": {"frames_per_collective": gatherer.batch, "collectives": gatherer.stats["gathers"],
+                       "bytes_into_root_per_collective": gatherer.stats["bytes_per_gather"],
+                       "host_ms_issuing_per_collective": (gatherer.stats["host_s_in_gather_calls"] * 1e3 /
+                                                          max(1, gatherer.stats["gathers"])),
+                       "host_ms_waiting_for_staging_ring": gatherer.stats["host_s_waiting_for_ring"] * 1e3,
+                       "tail_ms_after_last_frame_was_submitted": drain_s * 1e3},
+        }
+    if selftest:
+        if rank == 0:
+            line.update({"data": "selftest-cpu (stand-in frames over gloo: launcher / sharding / gather plumbing only)",
+                         "config": {"workload": "selftest", "parallelism": f"frames x{world}"},
+                         "roofline": None, "selftest": True})
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- secondary measurements (N = 1 only; every one is K timed steps of its own) -----------------------
+    secondary = {}
+    if world == 1:
         from gsplat.rendering import rasterization
+        from street_crafter_amd.pipeline import render_novel_view_u8
         op1 = scene.opacities[:, 0].contiguous()
 
-        def fused_step(s):
+        def fresh():
+            return FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch)
+
+        def fused_into(s, out, events=None, intermediates=False):
             cam = cams[s]
             with torch.no_grad():
                 rc, _, _ = rasterization(scene.means, scene.quats, scene.scales, op1, scene.sh, cam.viewmat[None],
                                          cam.K[None], W, H, near_plane=cam.znear, far_plane=cam.zfar,
                                          sh_degree=scene.sh_degree, render_mode="RGB+ED",
                                          rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
-                return to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1))
+                to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1), out=out)
 
-        for s in range(args.warmup):
-            fused_step(s)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        fused_frames = [fused_step(s) for s in range(args.warmup, total_steps)]
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
-        same = all(torch.equal(a, b) for a, b in zip(frames, fused_frames))
-        fused_line = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
-                      "frames_identical_to_caller_sequence": bool(same),
-                      "what": "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
-                              "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 4)"}
-        del fused_frames
+        def measure(step_fn, n_str, what, compare=None):
+            el, _, fr = timed_run(step_fn, fresh(), n_str, probes=False)
+            d = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
+                 "frames_in_flight": n_str, "what": what}
+            if compare is not None:
+                d["frames_identical_to_headline"] = bool(all(torch.equal(a, b) for a, b in zip(compare, fr)))
+            return d, fr
 
-    # Secondary (N = 1 only): the same K frames with TWO frames in flight, frame f on HIP stream f % 2.
-    # Frames are independent (that is what the multi-GPU sharding relies on); the second stream lets the
-    # latency-bound intersection kernels of one frame run under the VALU-bound rasterizer of the other.
-    # Not the headline: with overlapped frames per-operator durations (and so `roofline`) lose their meaning.
-    overlap_line = None
-    if world == 1 and not args.no_overlap:
-        two = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        if "single_stream" not in skip and n_streams > 1:
+            # round 1's headline configuration: one frame at a time on one stream
+            secondary["single_stream"], _ = measure(render_into, 1, "reference caller sequence, ONE frame in flight "
+                                                    "(round 1's headline configuration)", frames)
+        if "fused" not in skip:
+            secondary["fused_rasterization"], _ = measure(
+                fused_into, n_streams, "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
+                "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 7)", frames)
+            if n_streams > 1:
+                secondary["fused_rasterization"]["single_stream"], _ = measure(fused_into, 1, "same, one frame in flight")
+        if "two_pass" not in skip and not args.scene_ply:
+            # render_novel_view's frame (renderer.py:136-163): foreground pass + sky pass + composite
+            from street_crafter_amd.scenes import make_street_scene
+            _, sky = make_street_scene(64, n_sky=max(1000, args.n_gauss // 32), sh_degree=args.sh_degree)
+            sky = sky.to(dev)
 
-        def timed_overlapped(fn):
-            for s in range(args.warmup):
-                with torch.cuda.stream(two[s % 2]):
-                    fn(s)
+            def two_pass_into(s, out, events=None, intermediates=False):
+                render_novel_view_u8(scene, sky, cams[s], out=out, fused=False)
+
+            def two_pass_fused_into(s, out, events=None, intermediates=False):
+                render_novel_view_u8(scene, sky, cams[s], out=out, fused=True)
+
+            d, fr = measure(two_pass_into, n_streams, f"render_novel_view frame: S-{args.n_gauss // 1000}k foreground pass + "
+                            f"{sky.n}-Gaussian sky pass (radii of hundreds of px) + fused composite/clamp/uint8; "
+                            "caller sequence per pass")
+            d2, fr2 = measure(two_pass_fused_into, n_streams, "same, each pass through the fused rasterization()")
+            d["fused_rasterization"] = d2
+            d["fused_frames_identical"] = bool(all(torch.equal(a, b) for a, b in zip(fr, fr2)))
+            secondary["two_pass_frame"] = d
+            del fr, fr2, sky
+        if "street" not in skip and not args.scene_ply:
+            # street-SHAPED scenes (ground plane, facades, horizon band, big soft splats): super-tiles far above
+            # the in-LDS sort capacity and splat radii of hundreds of pixels, at 1x and 3x the headline size
+            from street_crafter_amd.scenes import make_street_scene
+            secondary["street_scene"] = {}
+            for n_st in (args.n_gauss, 3 * args.n_gauss):
+                fg, sky = make_street_scene(n_st, sh_degree=args.sh_degree)
+                fg, sky = fg.to(dev), sky.to(dev)
+                ev_st = {}
+
+                def street_into(s, out, events=None, intermediates=False, fg=fg, ev_st=ev_st):
+                    with torch.no_grad():
+                        o = render_gaussians(fg, cams[s], stage_events=ev_st if s % 8 == 0 else None,
+                                             return_intermediates=True)
+                        to_uint8_frame(o["rgb"], out=out)
+                    street_into.I = int(o["_isect_ids"].numel())
+
+                d, _ = measure(street_into, 1, f"street-shaped scene, {n_st} foreground Gaussians, caller sequence, one frame in flight")
+                torch.cuda.synchronize(dev)
+                d["n_isects"] = street_into.I
+                d["stage_ms"] = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev_st.items()}
+                key = (dev.index, 1, n_st, 16, math.ceil(W / 16), math.ceil(H / 16))
+                meta = rendering._BIN_LAST_META.get(key)
+                if meta:
+                    d["largest_super_tile_records"] = meta[2]
+                    d["isect_route"] = "bucketed"
+                else:
+                    d["isect_route"] = "radix (bucketed path returned SC_EUNSUPPORTED)"
+                secondary["street_scene"][f"n{n_st}"] = d
+                del fg, sky
+        if "train" not in skip and not args.scene_ply:
+            # SURVEY 8(d) secondary: forward + backward steps/s at the reference's training resolution
+            # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
+            # groups requiring grad, absgrad on -- the shape of BASELINE config 2.
+            from street_crafter_amd.scenes import make_camera
+            tw_, th_ = 1600, int(round(1600 * H / W))
+            tcam = make_camera(tw_, th_, 2050.0 * tw_ / 1920.0, 2050.0 * tw_ / 1920.0).to(dev)
+            tscene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)
+            tparams = (tscene.means, tscene.quats, tscene.scales, tscene.opacities, tscene.sh)
+            for t in tparams:
+                t.requires_grad_(True)
+            target = torch.rand(3, th_, tw_, device=dev)
+
+            def train_step():
+                for t in tparams:
+                    t.grad = None
+                out = render_gaussians(tscene, tcam, mode="train")
+                ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
+
+            for _ in range(3):
+                train_step()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            outs = []
-            for s in range(args.warmup, total_steps):
-                with torch.cuda.stream(two[s % 2]):
-                    outs.append(fn(s))
+            n_train = min(args.steps, 20)
+            for _ in range(n_train):
+                train_step()
             torch.cuda.synchronize()
-            return time.perf_counter() - t1, outs
+            el = time.perf_counter() - t1
+            secondary["train_fwd_bwd"] = {
+                "value": n_train / el, "unit": "steps/s", "ms_per_step": el / n_train * 1e3,
+                "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad"}
+            del tscene, tparams, target
 
-        def caller_step(s):
-            with torch.no_grad():
-                return to_uint8_frame(render_gaussians(scene, cams[s])["rgb"])
-
-        el, outs = timed_overlapped(caller_step)
-        overlap_line = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
-                        "frames_identical_to_single_stream": bool(all(torch.equal(a, b) for a, b in zip(frames, outs))),
-                        "what": "reference caller sequence, two frames in flight on two HIP streams"}
-        del outs
-        if fused_line is not None:
-            el, outs = timed_overlapped(fused_step)
-            overlap_line["fused_rasterization"] = {"value": args.steps / el, "ms_per_step": el / args.steps * 1e3}
-            del outs
-
-    # SURVEY 8(d) secondary (N = 1 only): forward + backward steps/s at the reference's training resolution
-    # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
-    # groups requiring grad, absgrad on -- the shape of BASELINE config 3.
-    train_line = None
-    if world == 1 and not args.no_train and not args.scene_ply:
-        from street_crafter_amd.scenes import make_camera
-        tw_, th_ = 1600, int(round(1600 * H / W))
-        tcam = make_camera(tw_, th_, 2050.0 * tw_ / 1920.0, 2050.0 * tw_ / 1920.0).to(dev)
-        tscene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)
-        tparams = (tscene.means, tscene.quats, tscene.scales, tscene.opacities, tscene.sh)
-        for t in tparams:
-            t.requires_grad_(True)
-        target = torch.rand(3, th_, tw_, device=dev)
-
-        def train_step():
-            for t in tparams:
-                t.grad = None
-            out = render_gaussians(tscene, tcam, mode="train")
-            ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
-
-        for _ in range(3):
-            train_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n_train = min(args.steps, 20)
-        for _ in range(n_train):
-            train_step()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t1
-        train_line = {"value": n_train / el, "unit": "steps/s", "ms_per_step": el / n_train * 1e3,
-                      "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad"}
-        del tscene, tparams, target
-
-    # per-operator device time from the HIP events recorded inside the timed region
+    # ---- per-operator device time from the probe frames' HIP events ----------------------------------------
+    torch.cuda.synchronize(dev)
     stage_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
     I_mean = sum(n_isects) / max(len(n_isects), 1)
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
-    dominant = max(stage_ms, key=stage_ms.get)
-    dom_bytes = stage_algorithmic_bytes(dominant, args.n_gauss, I_mean, P, T, K)
-    dom_gbs = dom_bytes / (stage_ms[dominant] * 1e-3) / 1e9
     b_alg = algorithmic_bytes(args.n_gauss, int(I_mean), W, H, 16, K)
-    device_ms = sum(stage_ms.values())
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        fps = args.steps * world / elapsed
-        traffic = None
+        fps = line["value"]
+        operators = {}
+        for k, ms in stage_ms.items():
+            by = stage_algorithmic_bytes(k, args.n_gauss, I_mean, P, T, K)
+            operators[k] = {"ms": ms, "algorithmic_bytes": by, "gb_per_s": by / (ms * 1e-3) / 1e9,
+                            "frac_of_hbm_peak": by / (ms * 1e-3) / HBM_PEAK, "kernels": OPERATOR_KERNEL.get(k)}
+        # the dominant KERNEL (not operator): the only operators that are one launch each are projection, SH and
+        # rasterize, and the intersection operator's largest kernel is shorter than the rasterizer (profiles/)
+        dom = "rasterize_to_pixels"
+        dom_ms = stage_ms[dom]
+        dom_bytes = stage_algorithmic_bytes(dom, args.n_gauss, I_mean, P, T, K)
+        traffic, traffic_src = None, None
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(dominant, {}).get(f"n{args.n_gauss}")
+                traffic = json.load(open(tj)).get(dom, {}).get(f"n{args.n_gauss}")
+                traffic_src = ("profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel from separate "
+                               "rocprofv3 --pmc passes of this command (committed; not re-measured in this run)")
             except Exception:
                 traffic = None
-        line = {
-            "metric": "frames/sec @1M Gaussians 1920x1280 + PSNR vs ref; 1/2/4/8 MI355X",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+        line.update({
             "config": {"workload": (f"scene file {os.path.basename(args.scene_ply)} ({args.n_gauss} Gaussians)"
                                     if args.scene_ply else f"S-{args.n_gauss // 1000}k") +
-                                   f" static gsplat forward raster, 1 cam {W}x{H}, "
-                                   f"sh_degree {args.sh_degree}, tile 16, RGB+depth, antialiased; one frame per "
-                                   f"GPU per step, uint8 frames gathered to rank 0",
+                                   f" static gsplat forward raster, 1 cam {W}x{H}, sh_degree {args.sh_degree}, "
+                                   f"tile 16, RGB+depth, antialiased; the reference caller's operator sequence -> "
+                                   f"uint8 frame; one frame per GPU per step, {n_streams} frames in flight per GPU, "
+                                   f"uint8 frames gathered to rank 0 {gatherer.batch} per collective",
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
-                       "isect_mode": rendering._ISECT_MODE["mode"], "parallelism": f"frames x{world}"},
-            "roofline": {"bound": "hbm", "kernel": dominant + " (operator; its kernels: DESIGN.md section 4)", "achieved": dom_gbs, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": dom_gbs / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": stage_ms[dominant]},
+                       "isect_mode": rendering._ISECT_MODE["mode"], "frames_in_flight": n_streams,
+                       "parallelism": f"frames x{world}"},
+            "roofline": {"bound": "hbm", "kernel": OPERATOR_KERNEL[dom],
+                         "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": dom_bytes / (dom_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                         "launches_timed": len(events.get(dom, [])),
+                         "how": "HIP events around the rasterize_to_pixels operator (= this one kernel launch) on "
+                                "the probe frames of the timed region, each rendered alone on its stream; "
+                                "algorithmic bytes = 44 B x I (id + xy + opacity + conic + colour gathered per "
+                                "intersection) + 24 B x P (SURVEY 8d)",
+                         "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound. Tiles "
+                                 "terminate after ~12 % of their lists, so the bytes it really moves are ~0.1 of the "
+                                 "algorithmic figure (`traffic`); its floor is VALU issue: ~60 wave-instructions + "
+                                 "4 v_exp_f32 per blended splat per tile (DESIGN.md section 4)"},
+            "operators": operators,
             "frame_roofline": {"algorithmic_bytes_per_frame": b_alg,
                                "hbm_bound_fps_per_gpu": HBM_PEAK / b_alg,
                                "frac_of_hbm_roofline_wall": (fps / world) / (HBM_PEAK / b_alg),
-                               "frac_of_hbm_roofline_device": (1e3 / device_ms) / (HBM_PEAK / b_alg),
                                "valu_pair_bound": 256 * I_mean},
             "stage_ms": stage_ms,
-        }
-        if frame_events:
-            fm = sorted(a.elapsed_time(b) for a, b in frame_events)
-            pick = lambda q: fm[min(len(fm) - 1, int(round(q * (len(fm) - 1))))]
-            line["frame_ms_device"] = {"p10": pick(0.1), "p50": pick(0.5), "p90": pick(0.9), "samples": len(fm),
-                                       "what": "HIP events around whole frames (every 8th timed step, the ones "
-                                               "that also carry the per-operator events)"}
-        if fused_line is not None:
-            line["fused_rasterization"] = fused_line
-        if overlap_line is not None:
-            line["two_frames_in_flight"] = overlap_line
-        if train_line is not None:
-            line["train_fwd_bwd"] = train_line
-        if world == 1 and not args.no_cpu_baseline:
-            import numpy as np
-
-            def hip_frame(sc, cam):
+            "frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in probe_ev]) or {}),
+                                "what": "HIP events around whole PROBE frames (rendered alone: the device time "
+                                        "of one frame, operators + torch glue + uint8 conversion)"},
+            "frame_latency_ms": {**(percentiles([a.elapsed_time(b) for a, b in frame_ev]) or {}),
+                                 "what": f"HIP events around every other timed frame, {n_streams} frames in flight "
+                                         "(latency of a frame while it shares the GPU; throughput is `value`)"},
+        })
+        line.update(secondary)
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
+            def hip_frame():
                 with torch.no_grad():
-                    o = render_gaussians(sc.to(dev), cam.to(dev), return_intermediates=True)
+                    o = render_gaussians(scene, cams[0], return_intermediates=True)
                 return {"rgb": o["rgb"].permute(1, 2, 0).cpu().numpy(), "isect_ids": o["_isect_ids"].cpu().numpy(),
-                        "flatten_ids": o["_flatten_ids"].cpu().numpy()}
+                        "flatten_ids": o["_flatten_ids"].cpu().numpy(), "radii": o["_radii"][0].cpu().numpy()}
 
-            dt, I100k, parity = cpu_baseline(W, H, hip_frame)
-            scale = I100k / max(I_mean, 1.0)
-            line["cpu_baseline"] = {
-                "value": (1.0 / dt) * scale, "unit": "frames/s", "cores": 1, "kind": "port",
-                "sample": f"oracle/gsplat_oracle.py (numpy, 1 thread) on ONE frame of S-100k {W}x{H} "
-                          f"(I={I100k}) took {dt:.2f} s; value = 1/that, scaled by I_100k/I_1M={scale:.4f} "
-                          f"to the S-1M unit (work ~ intersections)",
-                "measured_fps_at_100k": 1.0 / dt, "host_cpus": os.cpu_count()}
-            line["parity_100k"] = parity
+            line["cpu_baseline"], line["parity"] = cpu_baseline(scene, cams[0], W, H, hip_frame)
         if args.stage_times:
             print(json.dumps(stage_ms, indent=1), file=sys.stderr)
         print(json.dumps(line), flush=True)

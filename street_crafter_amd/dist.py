@@ -118,7 +118,7 @@ class FrameGatherer:
         self._single: Dict[int, torch.Tensor] = {}
         self._busy: List[Optional[object]] = [None] * self.ring    # outstanding work per ring entry
         self._events: Dict[int, object] = {}                      # round -> event on its stream (HIP only)
-        self._written: Dict[int, int] = {}                        # batch index -> rounds written
+        self._written: Dict[int, set] = {}                        # batch index -> slots written
         self._pending = []                                        # (work, batch index, n rounds, recv list)
         self._done: Dict[int, torch.Tensor] = {}                  # global frame -> tensor (dst only)
         self.stats = {"gathers": 0, "bytes_per_gather": 0, "host_s_in_gather_calls": 0.0,
@@ -162,14 +162,16 @@ class FrameGatherer:
             ev = torch.cuda.Event()
             ev.record()
             self._events[r] = ev
-        self._written[b] = self._written.get(b, 0) + 1
-        if self._written[b] == self.batch:
+        self._written.setdefault(b, set()).add(r % self.batch)
+        if len(self._written[b]) == self.batch:
             self._flush(b, self.batch)
 
     def _flush(self, b: int, n_rounds: int):
         e = b % self.ring
+        if self._written.pop(b) != set(range(n_rounds)):
+            raise RuntimeError("FrameGatherer: rounds must be submitted 0, 1, 2, ... without gaps "
+                               "(a partial batch is the LEADING part of its batch)")
         send = self._staging[e][:n_rounds]
-        del self._written[b]
         t0 = time.perf_counter()
         if self.device.type == "cuda":
             cur = torch.cuda.current_stream(self.device)
@@ -189,7 +191,7 @@ class FrameGatherer:
 
     def drain(self) -> List[torch.Tensor]:
         for b in sorted(self._written):
-            self._flush(b, self._written[b])
+            self._flush(b, len(self._written[b]))
         for work, b, n_rounds, recv in self._pending:
             work.wait()
             if recv is not None and self.keep:
@@ -205,7 +207,13 @@ class FrameGatherer:
         return [self._done[k] for k in sorted(self._done)]
 
     def reset(self):
+        """Forget the frames delivered so far; round numbering restarts at 0 (call after drain())."""
+        assert not self._pending and not self._written, "reset() needs a drained gatherer"
         self._done.clear()
+        self._single.clear()
+        self._events.clear()
+        for k in self.stats:
+            self.stats[k] = 0 if isinstance(self.stats[k], int) else 0.0
 
 
 def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,

@@ -44,18 +44,27 @@ def _worker(rank, world, port, n_frames, q):
         else:
             assert frames is None
         # a second, explicitly asynchronous use: submit everything, then drain once
-        g = FrameGatherer(dst=0)
+        # batches of 3 rounds through a ring of 2 staging buffers: full batches, a partial tail, ring reuse,
+        # frames written straight into the staging slot
+        g = FrameGatherer((12, 20, 3), "cpu", dst=0, batch=3, ring=2)
         for r, f in enumerate(frames_for_rank(n_frames, rank, world)):
-            g.submit(r, _fake_frame(f))
+            if r % 2:
+                g.slot(r).copy_(_fake_frame(f))
+                g.submit(r)
+            else:
+                g.submit(r, _fake_frame(f))
         out = g.drain()
         if rank == 0:
             q.put(("ok" if all(torch.equal(fr, _fake_frame(i)) for i, fr in enumerate(out)) else "mismatch2", len(out)))
+        else:
+            assert out == []
+        assert world == 1 or g.stats["gathers"] == -(-len(frames_for_rank(n_frames, rank, world)) // 3)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 8), (3, 6)])
+@pytest.mark.parametrize("world,n_frames", [(2, 8), (3, 6), (2, 26)])
 def test_sharded_render_and_gather_gloo(world, n_frames):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -74,13 +83,94 @@ def test_frame_to_rank_map():
     assert frames_for_rank(8, 0, 2) == [0, 2, 4, 6]
     assert frames_for_rank(8, 1, 2) == [1, 3, 5, 7]
     assert sorted(sum((frames_for_rank(24, r, 8) for r in range(8)), [])) == list(range(24))
-    with pytest.raises(ValueError):
-        render_sharded(3, lambda f: _fake_frame(f)) if False else (_ for _ in ()).throw(ValueError())
+
+
+def _worker_bad_count(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        try:
+            render_sharded(3, _fake_frame)          # 3 frames over 2 ranks: not a whole number of rounds
+            q.put("no error")
+        except ValueError as e:
+            q.put("ValueError" if "multiple of world size 2" in str(e) else f"wrong message: {e}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_render_sharded_rejects_a_frame_count_that_is_not_a_multiple_of_the_world_size():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bad_count, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == "ValueError" and q.get(timeout=5) == "ValueError"
 
 
 def test_single_process_path():
     frames = render_sharded(4, _fake_frame)
     assert len(frames) == 4 and all(torch.equal(fr, _fake_frame(i)) for i, fr in enumerate(frames))
-    u8 = to_uint8_frame(torch.tensor([[[0.0, 1.0]], [[0.5, 2.0]], [[-1.0, 0.25]]]))
+    u8 = to_uint8_frame(torch.tensor([[[0.0, 1.0]], [[0.5, 2.0]], [[-1.0, 0.25]]]), rounding="save_image")
     assert u8.shape == (1, 2, 3) and u8.dtype == torch.uint8
     assert u8[0, 0].tolist() == [0, 128, 0] and u8[0, 1].tolist() == [255, 255, 64]
+
+
+def test_uint8_rounding_modes_are_the_reference_formulas():
+    """'video' = `(rgb * 255).astype(np.uint8)` (street_gaussian_visualizer.py:97, base_visualizer.py:37: what
+    mode=novel_view keeps), 'save_image' = torchvision.utils.save_image's mul(255).add_(0.5).clamp_(0, 255)
+    .to(uint8) (visualizer :92); with and without the sky composite of renderer.py:152,159."""
+    import numpy as np
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.rand(3, 33, 47, generator=g) * 1.4 - 0.2          # some values outside [0, 1]
+    sky = torch.rand(3, 33, 47, generator=g) * 1.2 - 0.1
+    acc = torch.rand(1, 33, 47, generator=g)
+    for comp in (False, True):
+        if comp:
+            ref = torch.clamp(rgb.clamp(0, 1) + sky.clamp(0, 1) * (1 - acc), 0.0, 1.0)     # renderer.py:152,159
+            kw = dict(acc=acc[0], sky_rgb_chw=sky)
+        else:
+            ref, kw = rgb.clamp(0, 1), {}
+        video = (ref.numpy().transpose(1, 2, 0) * 255).astype(np.uint8)
+        png = ref.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+        assert np.array_equal(to_uint8_frame(rgb, rounding="video", **kw).numpy(), video)
+        assert np.array_equal(to_uint8_frame(rgb, rounding="save_image", **kw).numpy(), png)
+        assert np.array_equal(to_uint8_frame(rgb, **kw).numpy(), video)               # default: the video frames
+        assert (video != png).mean() > 0.2                                              # the modes really differ
+    with pytest.raises(ValueError):
+        to_uint8_frame(rgb, rounding="nearest")
+    with pytest.raises(ValueError):
+        to_uint8_frame(rgb, acc=acc[0])
+
+
+def test_bench_launches_its_own_ranks_selftest():
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks (gloo, CPU stand-in frames),
+    frames are sharded, gathered in batches, checked on rank 0, and ONE JSON line comes out.  Same launcher /
+    sharding / gather / timing code as the GPU run; only the frame source and the backend differ."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None), env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--selftest-cpu", "--gpus", "2", "--steps", "21",
+                        "--warmup", "3", "--gather-batch", "4"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 21 and d["warmup"] == 3 and d["scaling"] == "weak" and d["selftest"]
+    assert len(d["per_rank_frames_per_s"]) == 2 and d["value"] > 0
+    assert d["gather"]["frames_per_collective"] == 4 and d["gather"]["collectives"] == 6      # ceil(21 / 4)
+    # asking for more GPUs than the machine has is a clear message and exit code 2, not an assert
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 2 and "exposes" in r.stderr
+    # a rank that dies takes the job down with its exit code
+    from street_crafter_amd.dist import launch_ranks
+    code = "import os,sys,time; sys.exit(7) if os.environ['RANK']=='1' else time.sleep(60)"
+    assert launch_ranks([sys.executable, "-c", code], 2) == 7

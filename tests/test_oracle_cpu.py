@@ -206,3 +206,76 @@ def test_oracle_reproduces_full_resolution_digest(golden_dir):
     assert ids.shape[0] == dg["n_isects"]
     for k, a in got.items():
         assert crc(a) == dg["crc32"][k], k
+
+
+# ---- the C/OpenMP restatement (checker at large sizes + bench.py's cpu_baseline) ----------------------
+@pytest.mark.parametrize("case", ["edge", "ragged", "sh3", "multicam"])
+def test_c_oracle_is_pinned_to_the_numpy_oracle(case):
+    """oracle/gsplat_oracle_c.c vs oracle/gsplat_oracle.py: every integer output and every projection / SH
+    float bit for bit; blended pixels up to libm's expf (1e-5 of the 1e-4 bar); the unstable-pixel flags equal."""
+    from oracle import gsplat_oracle_c as OC
+    from street_crafter_amd.scenes import make_edge_case_scene
+    if case == "multicam":
+        sc = make_scene(5000, seed=3, z_range=(1.0, 40.0), scale_range=(0.01, 0.5))
+        W, H, tw, th = 200, 120, 13, 8
+        m2l, rl, dl = [], [], []
+        for i in range(3):
+            c = make_camera(W, H, 220.0, 220.0, yaw=0.05 * i)
+            a = (sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), c.viewmat.numpy(), c.K.numpy(), W, H)
+            e = O.fully_fused_projection(*a, near_plane=0.001, far_plane=1000.0)
+            g = OC.fully_fused_projection(*a, near_plane=0.001, far_plane=1000.0)
+            for x, y in zip(e, g):
+                np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32))
+            m2l.append(e[1]); rl.append(e[0]); dl.append(e[2])
+        m2, r, d = np.stack(m2l), np.stack(rl), np.stack(dl)
+        for sort in (True, False):
+            e = O.isect_tiles(m2, r, d, 16, tw, th, sort=sort, n_cameras=3)
+            g = OC.isect_tiles(m2, r, d, 16, tw, th, sort=sort, n_cameras=3, return_offsets=True)
+            for x, y in zip(e, g[:3]):
+                np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(OC.isect_tiles(m2, r, d, 16, tw, th, return_offsets=True)[3],
+                                      O.isect_offset_encode(O.isect_tiles(m2, r, d, 16, tw, th, n_cameras=3)[1], 3, tw, th))
+        return
+    deg = 3 if case == "sh3" else 1
+    if case == "edge":
+        sc, cam = make_edge_case_scene(), make_camera(256, 160, 280.0, 280.0)
+    else:
+        sc = make_scene(6000, sh_degree=deg, seed=31, z_range=(1.0, 40.0), scale_range=(0.01, 0.3))
+        cam = make_camera(200, 120, 280.0, 280.0)          # ragged: last tile column / row partial
+    a = (sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(), sc.sh.numpy(),
+         cam.viewmat.numpy(), cam.K.numpy(), cam.width, cam.height, deg)
+    e = O.render_frame(*a, return_unstable=True)
+    OC.set_num_threads(3)
+    g = OC.render_frame(*a, return_unstable=True)
+    for k in ("radii", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "last_ids", "unstable"):
+        np.testing.assert_array_equal(e[k], g[k], err_msg=k)
+    for k in ("means2d", "depths", "conics", "compensations", "opacities", "colors"):
+        np.testing.assert_array_equal(e[k].view(np.uint32), g[k].view(np.uint32), err_msg=k)
+    ok = ~e["unstable"]
+    np.testing.assert_allclose(g["render_colors"][..., :3][ok], e["render_colors"][..., :3][ok], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(g["render_alphas"][ok], e["render_alphas"][ok], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(g["render_colors"][..., 3][ok], e["render_colors"][..., 3][ok], rtol=1e-5, atol=1e-4)
+    # other channel counts and a background
+    rng = np.random.default_rng(2)
+    cols = rng.uniform(0, 1, size=(1, sc.n, 7)).astype(np.float32)
+    bg = rng.uniform(0, 1, size=(1, 7)).astype(np.float32)
+    ra = (e["means2d"][None], e["conics"][None], cols, e["opacities"][None], cam.width, cam.height, 16,
+          e["isect_offsets"], e["flatten_ids"])
+    ee, gg = O.rasterize_to_pixels(*ra, backgrounds=bg, return_unstable=True), OC.rasterize_to_pixels(*ra, backgrounds=bg)
+    np.testing.assert_allclose(gg[0][~ee[3]], ee[0][~ee[3]], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(gg[2], ee[2])
+
+
+def test_two_pass_composite_and_quantisation_restatement():
+    """composite_sky / quantise_u8 are the reference's expressions (renderer.py:152,159; visualizer :92,:97)."""
+    rng = np.random.default_rng(9)
+    fg = rng.uniform(-0.2, 1.3, size=(5, 7, 3)).astype(np.float32)
+    sky = rng.uniform(-0.2, 1.3, size=(5, 7, 3)).astype(np.float32)
+    acc = rng.uniform(0, 1, size=(5, 7, 1)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a)
+    ref = torch.clamp(torch.clamp(t(fg), 0.0, 1.0) + torch.clamp(t(sky), 0.0, 1.0) * (1 - t(acc)), 0.0, 1.0).numpy()
+    got = O.composite_sky(fg, acc, sky)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+    np.testing.assert_array_equal(O.quantise_u8(got, "video"), (ref * 255).astype(np.uint8))
+    np.testing.assert_array_equal(O.quantise_u8(got, "save_image"),
+                                  t(ref).mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy())
