@@ -9,10 +9,13 @@ A "step" = every rank renders ONE frame of the synthetic S-1M scene (1 000 000 G
 1920x1280, SURVEY.md 8d / BASELINE.md 2) through the drop-in gsplat operators (the caller's
 sequence of street_gaussian_renderer.py:186-302, forward only) with a per-frame camera and turns it
 into the uint8 frame the novel-view loop keeps; finished frames are gathered to rank 0 (RCCL), K
-frames per collective.  Scene tensors are resident in HBM before the timed region.  Each rank keeps
-`--frames-in-flight` (default 2) independent frames in flight on as many HIP streams; every 8th
-timed frame is a PROBE frame rendered alone (all streams drained) with HIP events around every
-operator, which is where `roofline` and `stage_ms` come from.  Rank 0 prints ONE JSON line.
+frames per collective.  Scene tensors are resident in HBM before the timed region.  Every 8th timed frame is a PROBE frame
+with HIP events around every operator, which is where `roofline` and `stage_ms` come from.  At
+--gpus 1 one frame is in flight at a time (a probed kernel runs alone: its HIP-event time is the
+kernel's duration, as rocprofv3 reports it for the same command); at --gpus N > 1 every rank keeps
+`--frames-in-flight` (default 2) independent frames in flight on as many HIP streams (the
+`two_frames_in_flight` line of the N = 1 run is the per-GPU figure to compare with).
+Rank 0 prints ONE JSON line.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the
 GPU) starts the N ranks itself and forwards rank 0's line.
@@ -51,8 +54,10 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--sh-degree", type=int, default=1)
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="independent frames each rank keeps in flight (one HIP stream each)")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="independent frames each rank keeps in flight, one HIP stream each (default: 1 at "
+                         "--gpus 1, so that per-kernel HIP-event times describe a kernel running alone and agree "
+                         "with rocprofv3 of the same command; 2 at --gpus N > 1)")
     ap.add_argument("--gather-batch", type=int, default=8, help="frames per gather collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
@@ -60,7 +65,7 @@ def parse(argv=None):
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary measurement (keeps rocprof profiles of the headline clean)")
-    ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: single_stream,fused,"
+    ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: two_in_flight,fused,"
                                                "two_pass,street,train")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
@@ -217,10 +222,12 @@ def run_rank(args):
     from street_crafter_amd.dist import FrameGatherer, to_uint8_frame
     W, H = args.width, args.height
     total_steps = args.warmup + args.steps
+    if args.frames_in_flight is None:
+        args.frames_in_flight = 1 if world == 1 else 2
     n_streams = 1 if selftest else max(1, args.frames_in_flight)
     skip = set(x for x in args.skip.split(",") if x)
     if args.headline_only:
-        skip |= {"single_stream", "fused", "two_pass", "street", "train"}
+        skip |= {"two_in_flight", "fused", "two_pass", "street", "train"}
 
     if selftest:
         W, H = 64, 48
@@ -268,15 +275,14 @@ def run_rank(args):
             torch.cuda.synchronize(dev)
 
     def run_steps(first, last, timed, g, step_fn, n_str=n_streams, probes=True):
-        """steps [first, last): frame s on stream s % n_str; every 8th timed step is a probe frame, rendered
-        ALONE (streams drained before and after) with per-operator HIP events."""
+        """steps [first, last): frame s on stream s % n_str; every 8th timed step is a probe frame with
+        per-operator HIP events (no draining: with n_str > 1 a probed kernel shares the GPU with the other
+        stream's frame and its time says so)."""
         strs = streams[:n_str] if (streams is not None and n_str > 1) else None
         for s in range(first, last):
             r = s - first          # round number of this run (the gatherer is reset between runs)
             probe = probes and timed and ((s - first) % 8 == 0) and not selftest
-            if probe and strs is not None:
-                sync_streams()
-            ctx = torch.cuda.stream(strs[s % n_str]) if (strs is not None and not probe) else None
+            ctx = torch.cuda.stream(strs[s % n_str]) if strs is not None else None
             if ctx is not None:
                 ctx.__enter__()
             try:
@@ -294,8 +300,6 @@ def run_rank(args):
             finally:
                 if ctx is not None:
                     ctx.__exit__(None, None, None)
-            if probe and strs is not None:
-                sync_streams()
 
     def barrier():
         if world > 1:
@@ -387,16 +391,20 @@ def run_rank(args):
                 d["frames_identical_to_headline"] = bool(all(torch.equal(a, b) for a, b in zip(compare, fr)))
             return d, fr
 
-        if "single_stream" not in skip and n_streams > 1:
-            # round 1's headline configuration: one frame at a time on one stream
-            secondary["single_stream"], _ = measure(render_into, 1, "reference caller sequence, ONE frame in flight "
-                                                    "(round 1's headline configuration)", frames)
+        if "two_in_flight" not in skip:
+            if streams is None:
+                streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+            # what every rank of a --gpus N > 1 run does: frame f on HIP stream f % 2 (frames are independent; the
+            # latency-bound intersection kernels of one frame run under the VALU-bound rasterizer of the other)
+            secondary["two_frames_in_flight"], _ = measure(render_into, 2, "reference caller sequence, two frames in "
+                                                           "flight on two HIP streams (the per-rank configuration of a "
+                                                           "--gpus N > 1 run)", frames)
         if "fused" not in skip:
             secondary["fused_rasterization"], _ = measure(
-                fused_into, n_streams, "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
+                fused_into, 1, "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
                 "rasterize_mode='antialiased') -> uint8 frame; fused forward (DESIGN.md section 7)", frames)
-            if n_streams > 1:
-                secondary["fused_rasterization"]["single_stream"], _ = measure(fused_into, 1, "same, one frame in flight")
+            if "two_in_flight" not in skip:
+                secondary["fused_rasterization"]["two_frames_in_flight"], _ = measure(fused_into, 2, "same, two frames in flight")
         if "two_pass" not in skip and not args.scene_ply:
             # render_novel_view's frame (renderer.py:136-163): foreground pass + sky pass + composite
             from street_crafter_amd.scenes import make_street_scene
@@ -409,10 +417,10 @@ def run_rank(args):
             def two_pass_fused_into(s, out, events=None, intermediates=False):
                 render_novel_view_u8(scene, sky, cams[s], out=out, fused=True)
 
-            d, fr = measure(two_pass_into, n_streams, f"render_novel_view frame: S-{args.n_gauss // 1000}k foreground pass + "
+            d, fr = measure(two_pass_into, 1, f"render_novel_view frame: S-{args.n_gauss // 1000}k foreground pass + "
                             f"{sky.n}-Gaussian sky pass (radii of hundreds of px) + fused composite/clamp/uint8; "
                             "caller sequence per pass")
-            d2, fr2 = measure(two_pass_fused_into, n_streams, "same, each pass through the fused rasterization()")
+            d2, fr2 = measure(two_pass_fused_into, 1, "same, each pass through the fused rasterization()")
             d["fused_rasterization"] = d2
             d["fused_frames_identical"] = bool(all(torch.equal(a, b) for a, b in zip(fr, fr2)))
             secondary["two_pass_frame"] = d
@@ -426,6 +434,8 @@ def run_rank(args):
                 fg, sky = make_street_scene(n_st, sh_degree=args.sh_degree)
                 fg, sky = fg.to(dev), sky.to(dev)
                 ev_st = {}
+                key = (dev.index, 1, n_st, 16, math.ceil(W / 16), math.ceil(H / 16))
+                rendering._BIN_LAST_META.pop(key, None)          # (keyed by shape: S-1M's entry has the same key)
 
                 def street_into(s, out, events=None, intermediates=False, fg=fg, ev_st=ev_st):
                     with torch.no_grad():
@@ -438,7 +448,6 @@ def run_rank(args):
                 torch.cuda.synchronize(dev)
                 d["n_isects"] = street_into.I
                 d["stage_ms"] = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev_st.items()}
-                key = (dev.index, 1, n_st, 16, math.ceil(W / 16), math.ceil(H / 16))
                 meta = rendering._BIN_LAST_META.get(key)
                 if meta:
                     d["largest_super_tile_records"] = meta[2]
@@ -525,7 +534,9 @@ def run_rank(args):
                          "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                          "launches_timed": len(events.get(dom, [])),
                          "how": "HIP events around the rasterize_to_pixels operator (= this one kernel launch) on "
-                                "the probe frames of the timed region, each rendered alone on its stream; "
+                                "the probe frames of the timed region" + ("" if n_streams == 1 else
+                                f", {n_streams} frames in flight: the kernel shares the GPU with the other stream's "
+                                "frame while it is timed") + "; "
                                 "algorithmic bytes = 44 B x I (id + xy + opacity + conic + colour gathered per "
                                 "intersection) + 24 B x P (SURVEY 8d)",
                          "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound. Tiles "
@@ -538,12 +549,11 @@ def run_rank(args):
                                "frac_of_hbm_roofline_wall": (fps / world) / (HBM_PEAK / b_alg),
                                "valu_pair_bound": 256 * I_mean},
             "stage_ms": stage_ms,
-            "frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in probe_ev]) or {}),
-                                "what": "HIP events around whole PROBE frames (rendered alone: the device time "
-                                        "of one frame, operators + torch glue + uint8 conversion)"},
-            "frame_latency_ms": {**(percentiles([a.elapsed_time(b) for a, b in frame_ev]) or {}),
-                                 "what": f"HIP events around every other timed frame, {n_streams} frames in flight "
-                                         "(latency of a frame while it shares the GPU; throughput is `value`)"},
+            "frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in frame_ev]) or {}),
+                                "what": f"HIP events around every timed frame that is not a probe frame (operators + "
+                                        f"torch glue + uint8 conversion), {n_streams} frame(s) in flight"},
+            "probe_frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in probe_ev]) or {}),
+                                      "what": "the probe frames (10 more event pairs and the intermediates kept)"},
         })
         line.update(secondary)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:

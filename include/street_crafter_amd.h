@@ -157,11 +157,11 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                      float* render_colors, float* render_alphas,
                      int32_t* last_ids /* nullable: only the backward pass reads it */,
-                     void* workspace /* nullable: sc_rasterize_workspace_bytes(C,N,D) bytes */,
+                     void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
-/* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a
- * kernel with scratch needs no ABI change) */
-size_t sc_rasterize_workspace_bytes(int C, int N, int D);
+/* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
+ * with scratch needs no ABI change) */
+size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height);
 /* Gradient outputs must be ZERO-FILLED by the caller (the kernel accumulates with atomics).
  * v_means2d_abs nullable (absgrad). */
 int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
@@ -227,6 +227,8 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
 /* Select a kernel variant at run time (for A/B measurements in one process).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats; generic fallback / cross-check),
  *                     3 = one wave per tile, 4 pixels per lane, exact tile-level cull (default)
+ *   key "raster_map": block -> tile map of the wave rasterizer: 1 = neighbouring tiles round-robin over the
+ *                     8 XCDs (default), 0 = one band of tile rows per XCD
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)

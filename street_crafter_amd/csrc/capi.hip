@@ -34,6 +34,12 @@ extern "C" int sc_set_option(const char* key, int value) {
         g_sc_raster_bwd_variant = value;
         return prev;
     }
+    if (strcmp(key, "raster_map") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_raster_map;
+        g_sc_raster_map = value;
+        return prev;
+    }
     if (strcmp(key, "raster_fwd") == 0) {
         if (value != 0 && value != 3) return SC_EINVAL;
         const int prev = g_sc_raster_fwd_variant;

@@ -230,15 +230,15 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode) {
     constexpr int SB = 2;
     constexpr int B = 64 * SB;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, log2(op), A2
     __shared__ float4 bck_s[B + 1];       // B2, C2, sorted index (int bits), flat id (int bits)
     __shared__ float4 col_s[B + 1];
 
-    int tflat;
-    {
+    int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map")
+    if (map_mode == 0) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
         tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -468,7 +468,8 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
     hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d, conics,   \
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \
                        total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,            \
-                       v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities)
+                       v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities,    \
+                       g_sc_raster_map)
         if (D == 4) SC_LAUNCH_BWD_WAVE(4);
         else SC_LAUNCH_BWD_WAVE(3);
 #undef SC_LAUNCH_BWD_WAVE

@@ -122,57 +122,60 @@ __global__ void raster_fwd_ref_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// variant 3: ONE WAVE PER TILE, four pixels per lane (lane l owns pixels x = 4*(l&3)..+3 of row
-// l>>2 of the 16x16 tile).  Measured on variant 2 the blend loop was co-bound by the LDS
-// broadcast reads of the splat record (3 x ds_read_b128 per splat per wave, 4 waves per tile)
-// and by VALU; with one wave per tile each record is read once per tile instead of four times,
-// dy-dependent terms are shared by the lane's four pixels, there is no workgroup barrier at all
-// (the workgroup IS the wave), the whole-tile early exit is a single wave vote, and up to 32
-// tiles are resident per CU to hide the gather latency.  The lane stores its four pixels as
-// 64 contiguous bytes.  Same pinned arithmetic -> bit-identical to variant 0.
+// variant 3: ONE WAVE PER TILE, four pixels per lane (lane l owns x = 4*(l&3)..+3 of row l>>2 of the
+// 16x16 tile).  Measured on the 4-wave form the blend loop was co-bound by the LDS broadcast reads of
+// the splat record (3 x ds_read_b128 per splat per wave, 4 waves per tile) and by VALU; with one
+// wave per tile each record is read once per tile instead of four times, dy-dependent terms are
+// shared by the lane's pixels, there is no workgroup barrier at all (the workgroup IS the wave),
+// the early exit is a single wave vote, and up to 32 tiles are resident per CU to hide the gather
+// latency.  Same pinned arithmetic -> bit-identical to variant 0.
+// The body is templated on the part of a tile one wave covers (NSUB = 1 whole tile, 2 = a half: 16x8,
+// 2 pixels per lane, 4 = a quarter); only NSUB = 1 is instantiated: cutting tiles into half-tile waves
+// behind a heavy-first work list was measured (tools/exp_raster.py, profiles/r02_raster_policy_ab.txt)
+// and costs 30 us on S-1M (staging and LDS reads double) for -60 us on the street scene, whose real
+// problem was the block -> tile map (see the kernel).
 // ------------------------------------------------------------------------------------------
 // TRACK: record last_ids (the sorted index of the last splat each pixel blended), needed only by
 // the backward pass; inference launches the variant without it.
-template <int CDIM, bool TRACK>
-__global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
+// NSUB: 1 = whole tile, 2 = half (8 rows), 4 = quarter (4 rows); `sub` = which one.
+template <int CDIM, bool TRACK, int NSUB>
+__device__ __forceinline__ void raster_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg) {
+    int32_t* __restrict__ last_ids, int dbg, int tflat, int sub,
+    float4* xyoa_s, float4* bck_s, float4* col_s) {
     constexpr int SB = 2;                 // splats staged per lane per batch
     constexpr int B = 64 * SB;            // batch size
-    __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
-    __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
-    __shared__ float4 col_s[B + 1];       // colour channels
+    constexpr int NP = NSUB == 1 ? 2 : 1; // pixel PAIRS per lane
+    constexpr int PPL = NSUB == 1 ? 4 : (NSUB == 2 ? 2 : 1);   // live pixels per lane
+    constexpr int ROWS = 16 / NSUB;       // rows of the tile this wave covers
 
-    int tflat;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     const int tiles_per_cam = tile_width * tile_height;
     const int cam = tflat / tiles_per_cam;
     const int tile_id = tflat - cam * tiles_per_cam;
     const int tyi = tile_id / tile_width, txi = tile_id - tyi * tile_width;
     const int lane = threadIdx.x;
-    const int px0_i = txi * 16 + 4 * (lane & 3), py_i = tyi * 16 + (lane >> 2);
+    // lane -> pixels: 16 / PPL lanes per row
+    const int lanes_per_row = 16 / PPL;
+    const int row = sub * ROWS + lane / lanes_per_row;
+    const int px0_i = txi * 16 + PPL * (lane % lanes_per_row), py_i = tyi * 16 + row;
     const float py = (float)py_i + 0.5f;
-    float pxf[4];
-    bool inside[4];
+    float pxf[2 * NP];
+    bool inside[2 * NP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2 * NP; ++k) {
         pxf[k] = (float)(px0_i + k) + 0.5f;
-        inside[k] = (px0_i + k < width) && (py_i < height);
+        inside[k] = (k < PPL) && (px0_i + k < width) && (py_i < height);
     }
     const int64_t pix0 = ((int64_t)cam * height + py_i) * width + px0_i;
 
     if (tile_masks && !tile_masks[tflat]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PPL; ++k) {
             if (inside[k]) {
 #pragma unroll
                 for (int d = 0; d < CDIM; ++d)
@@ -187,36 +190,38 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
 
+    // the rectangle of pixel centres this wave owns (only pixels inside the image count)
     const float rx0 = (float)(txi * 16) + 0.5f;
-    const float ry0 = (float)(tyi * 16) + 0.5f;
+    const float ry0 = (float)(tyi * 16 + sub * ROWS) + 0.5f;
     const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
-    const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
+    const float ry1 = (float)min(tyi * 16 + sub * ROWS + ROWS - 1, height - 1) + 0.5f;
 
-    // Per-pixel state in PAIRS (v_pk_add / v_pk_fma / v_pk_mul process two pixels per VALU op; the blend
-    // loop is VALU-bound).  A finished pixel (terminated, or outside the image) is marked by poisoning
-    // its x coordinate with +inf: dx = -inf, sigma2 = +inf, alpha = exp2(-inf) = 0 < 1/255, so it can
-    // never blend again and the loop needs no per-pixel `done` flag or mask bookkeeping at all.
+    // Per-pixel state in PAIRS (v_pk_add / v_pk_fma / v_pk_mul process two pixels per VALU op).
+    // A finished pixel (terminated, outside the image, or the unused second pixel of a quarter-tile
+    // lane) is marked by poisoning its x coordinate with +inf: dx = -inf, sigma2 = +inf, alpha =
+    // exp2(-inf) = 0 < 1/255, so it can never blend again and the loop needs no per-pixel `done` flag.
     // (A2 == 0 would turn that into 0 * inf = NaN, hence the staging replaces an exactly-zero A2 by
     // 1e-37, which no finite pixel can see: 1e-37 * dx^2 is absorbed by every other term.)
     const float INF = __builtin_huge_valf();
-    sc_f2 pxp[2], T2[2];
-    int cur[4] = {0, 0, 0, 0};
-    float acc[4][CDIM];
+    sc_f2 pxp[NP], T2[NP];
+    int cur[2 * NP];
+    float acc[2 * NP][CDIM];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < NP; ++p) {
         pxp[p] = sc_f2{inside[2 * p] ? pxf[2 * p] : INF, inside[2 * p + 1] ? pxf[2 * p + 1] : INF};
         T2[p] = sc_f2{1.f, 1.f};
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 2 * NP; ++k) {
+        cur[k] = 0;
 #pragma unroll
         for (int d = 0; d < CDIM; ++d) acc[k][d] = 0.f;
     }
     // x coordinates are positive floats or +inf, so their bit patterns order like integers
     // (integer min: no NaN canonicalisation ops)
     auto all_done = [&]() -> bool {
-        const int m = min(min(__float_as_int(pxp[0].x), __float_as_int(pxp[0].y)),
-                          min(__float_as_int(pxp[1].x), __float_as_int(pxp[1].y)));
+        int m = min(__float_as_int(pxp[0].x), __float_as_int(pxp[0].y));
+        if (NP > 1) m = min(m, min(__float_as_int(pxp[NP - 1].x), __float_as_int(pxp[NP - 1].y)));
         return __all(m == 0x7f800000);
     };
 
@@ -288,10 +293,10 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             for (int t = 0; t < bsz; ++t) {
                 const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
                 const float dy = a.y - py;
-                const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the 4 pixels
+                const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the lane's pixels
                 const int sidx = __float_as_int(bc.z);
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     // the pinned arithmetic of raster_common.h, two pixels per instruction
                     const sc_f2 dx = sc_f2{a.x, a.x} - pxp[p];
                     const sc_f2 tt = __builtin_elementwise_fma(sc_f2{a.w, a.w}, dx, sc_f2{bdy, bdy});
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
                     // adding c*0 leaves the sums bit-identical to skipping (sums are never -0)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
+                        if (2 * p + h >= PPL) continue;        // the unused pixel of a quarter-tile lane
                         const float vh = h ? vis.y : vis.x;
                         acc[2 * p + h][0] = __fmaf_rn(c.x, vh, acc[2 * p + h][0]);
                         acc[2 * p + h][1] = __fmaf_rn(c.y, vh, acc[2 * p + h][1]);
@@ -326,36 +332,68 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
             }
         }
     }
-    const float T[4] = {T2[0].x, T2[0].y, T2[1].x, T2[1].y};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PPL; ++k) {
         if (!inside[k]) continue;
+        const float Tk = (k & 1) ? T2[k >> 1].y : T2[k >> 1].x;
         const int64_t pix = pix0 + k;
-        render_alphas[pix] = 1.0f - T[k];
+        render_alphas[pix] = 1.0f - Tk;
         if (CDIM == 4) {
             float4 o = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
             if (backgrounds) {
-                o.x += T[k] * backgrounds[cam * 4 + 0]; o.y += T[k] * backgrounds[cam * 4 + 1];
-                o.z += T[k] * backgrounds[cam * 4 + 2]; o.w += T[k] * backgrounds[cam * 4 + 3];
+                o.x += Tk * backgrounds[cam * 4 + 0]; o.y += Tk * backgrounds[cam * 4 + 1];
+                o.z += Tk * backgrounds[cam * 4 + 2]; o.w += Tk * backgrounds[cam * 4 + 3];
             }
             // "RGB+ED" epilogue (sc_rasterize_fwd_ed): expected depth = depth sum / max(alpha, 1e-10),
             // the caller's renderer.py:284 / gsplat rasterization() post-step, as one IEEE divide
-            if (dbg & 0x100) o.w = o.w / fmaxf(1.0f - T[k], 1e-10f);
+            if (dbg & 0x100) o.w = o.w / fmaxf(1.0f - Tk, 1e-10f);
             *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
         } else {
 #pragma unroll
             for (int d = 0; d < CDIM; ++d)
-                render_colors[pix * CDIM + d] = backgrounds ? acc[k][d] + T[k] * backgrounds[cam * CDIM + d] : acc[k][d];
+                render_colors[pix * CDIM + d] = backgrounds ? acc[k][d] + Tk * backgrounds[cam * CDIM + d] : acc[k][d];
         }
         if (TRACK) last_ids[pix] = cur[k];
     }
 }
 
+template <int CDIM, bool TRACK>
+__global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
+    int width, int height, int tile_width, int tile_height, int total_tiles,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    float* __restrict__ render_colors, float* __restrict__ render_alphas,
+    int32_t* __restrict__ last_ids, int dbg, int map_mode) {
+    constexpr int B = 128;
+    __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
+    __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
+    __shared__ float4 col_s[B + 1];       // colour channels
+    // block -> tile.  Blocks b, b + 8, b + 16, .. share an XCD (and its 4 MiB L2).
+    //   map_mode 1 (default): tile = block, i.e. neighbouring tiles go round-robin over the 8 XCDs.  A dense
+    //     image region (the horizon band of a street scene) is then spread over all XCDs.
+    //   map_mode 0: one contiguous band of tile rows per XCD (more L2 reuse of the gathered parameters; but
+    //     the XCD that owns the dense band finishes long after the others: 0.49 vs 0.33 ms on the street scene,
+    //     no difference on the uniform S-1M).
+    int tflat = blockIdx.x;
+    if (map_mode == 0) {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    raster_item<CDIM, TRACK, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+                                tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
+                                render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s);
+}
+
 }  // namespace
 
-extern "C" size_t sc_rasterize_workspace_bytes(int C, int N, int D) {
-    (void)C; (void)N; (void)D;
-    return 256;       // the shipped kernels need no scratch (round 1's packed-record variant did: 64 B x C x N)
+int g_sc_raster_map = 1;      // sc_set_option "raster_map": block -> tile map of the wave kernel (see there)
+
+extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {
+    (void)C; (void)tile_width; (void)tile_height;
+    return 256;       // the shipped kernels need no scratch
 }
 
 static int rasterize_fwd_impl(const float* means2d, const float* conics, const float* colors,
@@ -388,7 +426,7 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,        \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
-                       render_alphas, last_ids, kdbg)
+                       render_alphas, last_ids, kdbg, g_sc_raster_map)
         if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
         else { if (last_ids) SC_LAUNCH_WAVE(3, true); else SC_LAUNCH_WAVE(3, false); }
 #undef SC_LAUNCH_WAVE

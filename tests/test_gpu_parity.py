@@ -835,6 +835,53 @@ def test_scene_files_drive_the_renderer(ops, tmp_path):
 
 
 # ---- knn ------------------------------------------------------------------------------------------
+def test_novel_view_two_pass_frame_vs_oracle(ops):
+    """render_novel_view (street_gaussian_renderer.py:136-163): foreground pass, sky pass (render_sky :80-93),
+    rgb + rgb_sky * (1 - acc), clamp.  Per pass: integer outputs bit-exact vs the oracle; composite <= 1e-4 on the
+    pixels stable in both passes; the fused composite + clamp + uint8 kernel equals the torch composition bit for
+    bit in both of the reference's rounding modes; the rasterization()-based fast path gives the same frame."""
+    from street_crafter_amd.dist import to_uint8_frame
+    from street_crafter_amd.pipeline import render_novel_view, render_novel_view_u8
+    from street_crafter_amd.scenes import make_street_scene
+    W, H = 320, 208
+    cam = make_camera(W, H, 340.0, 340.0)
+    fg, sky = make_street_scene(12000, n_sky=1000, seed=3)
+    as_dict = lambda sc: dict(means=sc.means.numpy(), quats=sc.quats.numpy(), scales=sc.scales.numpy(),
+                              opacities=sc.opacities.numpy(), sh=sc.sh.numpy(), sh_degree=sc.sh_degree)
+    exp = O.render_novel_view(as_dict(fg), as_dict(sky), cam.viewmat.numpy(), cam.K.numpy(), W, H,
+                              near_plane=cam.znear, far_plane=cam.zfar, return_unstable=True)
+    assert int(exp["sky"]["radii"].max()) > 60 and exp["sky"]["isect_ids"].shape[0] > 3000       # big sky splats
+    fgd, skyd, camd = fg.to(DEV), sky.to(DEV), cam.to(DEV)
+    with torch.no_grad():
+        out = render_novel_view(fgd, skyd, camd, return_intermediates=True)
+    for o, e in ((out, exp["fg"]), (out["_sky"], exp["sky"])):
+        np.testing.assert_array_equal(_np(o["_radii"])[0], e["radii"])
+        np.testing.assert_array_equal(_np(o["_isect_ids"]), e["isect_ids"])
+        np.testing.assert_array_equal(_np(o["_flatten_ids"]), e["flatten_ids"])
+        np.testing.assert_array_equal(_np(o["_isect_offsets"]), e["isect_offsets"])
+    ok = ~(exp["fg"]["unstable"][0] | exp["sky"]["unstable"][0])
+    assert (~ok).mean() < 0.01
+    rgb = _np(out["rgb"]).transpose(1, 2, 0)
+    np.testing.assert_allclose(rgb[ok], exp["rgb"][ok], rtol=0, atol=1e-4)
+    assert float(np.abs(rgb - np.clip(exp["fg"]["render_colors"][0, ..., :3], 0, 1))[ok].max()) > 0.05   # the sky shows
+    # one kernel instead of the torch expression: bit-identical, both rounding modes, straight from the raw images
+    fg_raw = out["_render_colors"][0, ..., :3].permute(2, 0, 1)
+    sky_raw = out["_sky"]["_render_colors"][0, ..., :3].permute(2, 0, 1)
+    acc = out["_render_alphas"][0, ..., 0]
+    for mode in ("video", "save_image"):
+        got = to_uint8_frame(fg_raw, acc=acc, sky_rgb_chw=sky_raw, rounding=mode)
+        np.testing.assert_array_equal(_np(got), O.quantise_u8(rgb, mode))
+        single = to_uint8_frame(fg_raw, rounding=mode)
+        np.testing.assert_array_equal(_np(single), O.quantise_u8(np.clip(_np(fg_raw).transpose(1, 2, 0), 0, 1), mode))
+    slot = torch.empty((H, W, 3), dtype=torch.uint8, device=DEV)
+    for fused in (False, True):
+        u8 = render_novel_view_u8(fgd, skyd, camd, out=slot, fused=fused)
+        assert u8.data_ptr() == slot.data_ptr()
+        np.testing.assert_array_equal(_np(u8), O.quantise_u8(rgb, "video"))
+    np.testing.assert_array_equal(_np(render_novel_view_u8(fgd, None, camd)),
+                                  O.quantise_u8(np.clip(_np(fg_raw).transpose(1, 2, 0), 0, 1), "video"))
+
+
 def test_knn_golden_bit_exact(golden_dir):
     from simple_knn._C import distCUDA2
     g = _load(golden_dir, "knn_small.npz")
