@@ -105,8 +105,11 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
  *                        meta_dev[2] > rec_capacity or meta_dev[3] > super_capacity, so a caller may
  *                        launch with predicted sizes before it has read meta_dev back (no GPU idle
  *                        bubble) and retry with exact sizes if the prediction was too small.
+ *                        A super-tile bucket of up to 3584 records is sorted by one workgroup in LDS; when
+ *                        super_capacity is larger, longer buckets are first cut into depth ranges that fit
+ *                        (only they pay for it).
  * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384, C*N >= 2^28 or
- * super_capacity > 7168; the caller then takes the count/emit/radix-sort route.
+ * super_capacity > 220 000; the caller then takes the count/emit/radix-sort route.
  */
 /* n_records < 0: bytes of the count-phase workspace (shared by both calls; holds the visible Gaussians'
  * rectangle / depth / id, 16 B each, in spatial order); n_records >= 0: bytes of the sort-phase workspace for that many records. */

@@ -452,29 +452,39 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
 // ---- pass 3: per-super-tile sort + emit ---------------------------------------------------------------
 constexpr int SS_THREADS = 512;
 constexpr int SS_WAVES = SS_THREADS / 64;
-constexpr int SS_MAX_CAP = 7168;                 // records of the largest super-tile this path sorts in LDS
-constexpr int SS_RPT = SS_MAX_CAP / SS_THREADS;  // records per thread held in registers (14)
+constexpr int SS_MAX_CAP = 3584;                 // records one workgroup sorts in LDS (3 workgroups per CU); longer buckets are SPLIT first
+constexpr int SS_RPT = SS_MAX_CAP / SS_THREADS;  // records per thread held in registers (7)
+constexpr int SS_NC = SS_THREADS;                // coarse bins of the two-level interpolation (one per thread)
+constexpr int64_t BIG_MAX_SUPER = 220000;        // largest super-tile the split path takes (limits its LDS tables)
 
-// Emits the per-tile lists of one super-tile from its records sorted on (depth, id) in LDS.
+// A SEGMENT is what one workgroup sorts: a whole super-tile's bucket, or one depth range of an oversized one.
+// tb[k] = entries of tile k (of the 2x2 super-tile) that precede this segment in the tile's list.
+struct Segment { int start, n, sb, heavy; int tb[4]; };
+
+__device__ __forceinline__ unsigned long long rec_key60(uint2 r) {      // (depth bits, flat id): the sort key
+    return ((unsigned long long)r.x << 28) | (unsigned long long)(r.y & ID_MASK);
+}
+
+// Emits the per-tile lists of one segment from its records sorted on (depth, id) in LDS.
 // Stable filter per tile: rank of record i in tile k's list = number of records j < i with mask bit k;
 // computed per (round, wave) with ballots, bases by a tiny scan over the (round, wave) table.
 // `order` (nullable): when given, the sorted sequence is S[order[0]], S[order[1]], ... (the
 // interpolation sort keeps 2-byte ranks instead of a second copy of the keys: 14 instead of 20 B of LDS
-// per record, i.e. three resident workgroups per CU instead of two)
+// per record).  tb: see Segment.  totals (nullable, LDS [4]): receives the segment's per-tile counts.
 template <int THREADS>
 __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict__ S,
                                            const unsigned short* __restrict__ order, int n, int sb, const Geo& g,
                                            const int32_t* __restrict__ offsets, int n_tiles_total,
-                                           int64_t n_isects, int tile_bits, unsigned long long* table,
+                                           int64_t n_isects, int tile_bits, const int* tb, unsigned long long* table,
                                            int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
-                                           int dbg) {
+                                           unsigned* totals, int dbg) {
     constexpr int WAVES = THREADS / 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cam = sb / g.ST, srem = sb - cam * g.ST;
     const int sy = srem / g.stw, sx = srem - sy * g.stw;
     const int ntile = g.ss ? 4 : 1;
     const int rounds = (n + THREADS - 1) / THREADS;
-    // pass A: per (round, wave) packed counts (16 bits per tile; a tile list has <= 9216 entries)
+    // pass A: per (round, wave) packed counts (16 bits per tile; a segment has <= SS_MAX_CAP records)
     for (int r = 0; r < rounds; ++r) {
         const int i = r * THREADS + t;
         const unsigned m = (i < n) ? (unsigned)((S[order ? order[i] : i] >> 28) & 0xfu) : 0u;
@@ -496,6 +506,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
             if (i < cnt) table[i] = carry + incl - v;
             carry += (unsigned long long)__shfl((long long)incl, 63, 64);
         }
+        if (totals && lane < 4) totals[lane] = (unsigned)((carry >> (16 * lane)) & 0xffffu);
     }
     __syncthreads();
     // tile bases
@@ -508,7 +519,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
         tok[k] = (k < ntile) && tx < g.tile_width && ty < g.tile_height;
         const int tile = ty * g.tile_width + tx;
         const int tflat = cam * g.T + tile;
-        tbase[k] = tok[k] ? offsets[tflat] : 0;
+        tbase[k] = tok[k] ? offsets[tflat] + tb[k] : 0;
         // end of this tile's list: a write is dropped rather than allowed past it, so that records
         // whose masks disagree with the counts (corrupt input, diagnostic skips) cannot go out of bounds
         tend[k] = tok[k] ? ((tflat + 1 < n_tiles_total) ? offsets[tflat + 1] : (int)n_isects) : 0;
@@ -534,240 +545,437 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     }
 }
 
-// interpolation sort: the common path.  Records are spread over `nbk` sub-buckets by a MONOTONE map
-// of the depth bit pattern, grouped by one counting pass, and ranked inside their sub-bucket by
-// counting smaller (depth, id) keys.  A super-tile whose keys pile up in one sub-bucket (occupancy
-// > BS_MAX_OCC, e.g. hundreds of equal depths) is flagged and left to super_radix_kernel.
-constexpr int BS_MAX_OCC = 48;
+// LDS of the sort: [B: cap u64][order: cap u16][boff: cap + 2 u32][coarse: SS_NC u32][table][totals 4 u32]
+// (14 B per record + 2.6 KiB: three workgroups per CU up to cap = 3584)
+__host__ __device__ inline size_t sort_lds_bytes(int cap) {
+    const size_t table = (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64;
+    return (size_t)cap * 10 + (size_t)((cap + 4) & ~1) * 4 + (size_t)SS_NC * 4 + table + 16;
+}
 
-__global__ __launch_bounds__(SS_THREADS) void super_sort_kernel(
-    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
-    Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
-    int64_t rec_capacity, int64_t super_capacity, int tile_bits, int cap, int per_thread,
-    unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
+// Two-level interpolation sort of one segment (n <= cap <= SS_MAX_CAP records) on the 60-bit key
+// (depth bits, flat id), then the stable per-tile emit.
+//   level 1: SS_NC coarse bins by a MONOTONE linear map of the key over [lo, hi] (double precision: the
+//            map must be exactly non-decreasing in the key -- a correctly rounded u64 -> f64 conversion,
+//            one multiply, one truncation);
+//   level 2: a coarse bin that received c records is cut into c FINE buckets by the same map restricted to
+//            the bin -- a piecewise-linear equalisation, so a depth distribution with narrow clusters and
+//            far outliers (a facade plus sky, the normal case in a street scene) still averages about one
+//            record per fine bucket (round 1's single-level map piled such buckets hundreds deep and sent
+//            them to a slow radix fallback);
+//   counting sort into the n fine buckets, then every record is ranked inside its bucket by counting
+//   smaller keys.  Whatever the distribution the result is the exact order; only the cost of the ranking
+//   loop depends on it (equal depths are separated by the id bits of the key).
+__device__ __forceinline__ void sort_segment(
+    const uint2* __restrict__ recs, int n, int sb, const int* tb, int cap, const Geo& g,
+    const int32_t* __restrict__ offsets, int n_tbuckets, int64_t n_isects, int tile_bits,
+    unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out,
     int dbg) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    // [B: cap u64][order: cap u16][boff: SS_THREADS*per_thread + 1 u32][table]
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
     unsigned short* order = reinterpret_cast<unsigned short*>(B + cap);      // cap is a multiple of 256
-    unsigned* boff = reinterpret_cast<unsigned*>(order + cap);
-    const int nbk = SS_THREADS * per_thread;
-    unsigned long long* table = reinterpret_cast<unsigned long long*>(boff + ((nbk + 2) & ~1));
-    __shared__ unsigned red_lo[SS_WAVES], red_hi[SS_WAVES], red_sum[SS_WAVES], red_occ[SS_WAVES];
-
-    // the SAME three comparisons in every kernel of the sort phase and in the host wrapper
-    // (rendering._bin_launch_ran): a launch either runs in full or not at all
-    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
-    const int sb = blockIdx.x;
-    const int s = soffsets[sb];
-    const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
-    const int n = e - s;
-    if (n <= 0) return;
+    unsigned* boff = reinterpret_cast<unsigned*>(order + cap);              // [n + 1] fine-bucket counters
+    unsigned* coarse = boff + ((cap + 4) & ~1);       // [SS_NC] count in the low, first fine bucket in the high half
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(coarse + SS_NC);
+    unsigned* totals = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(table) +
+                                                   (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64);
+    __shared__ unsigned long long red_lo[SS_WAVES], red_hi[SS_WAVES];
+    __shared__ unsigned red_sum[SS_WAVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    for (int i = t; i <= nbk; i += SS_THREADS) boff[i] = 0;
-    // the super-tile's records are read from global memory ONCE, all loads of a thread in flight
-    // together, and stay in registers for the min/max, counting and scatter passes
-    // (cap <= SS_MAX_CAP -> at most SS_RPT records per thread).  Phase times on S-1M (rocprof A/B):
-    // loads + min/max 17 us, counting +5, scan + scatter +10, ranking +24, emit +28.
+    for (int i = t; i <= n; i += SS_THREADS) boff[i] = 0;
+    coarse[t] = 0u;
+    // the segment's records are read from global memory ONCE, all loads of a thread in flight together,
+    // and stay in registers through the min/max, both counting passes and the scatter
     uint2 rec[SS_RPT];
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {
         const int i = t + k * SS_THREADS;
-        rec[k] = (i < n) ? records[s + i] : make_uint2(0u, 0u);
+        rec[k] = (i < n) ? recs[i] : make_uint2(0u, 0u);
     }
-    unsigned lo = 0xffffffffu, hi = 0u;
+    unsigned long long lo = ~0ull, hi = 0ull;
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {
-        if (t + k * SS_THREADS < n) { lo = min(lo, rec[k].x); hi = max(hi, rec[k].x); }
+        if (t + k * SS_THREADS < n) {
+            const unsigned long long K = rec_key60(rec[k]);
+            lo = K < lo ? K : lo;
+            hi = K > hi ? K : hi;
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-        lo = min(lo, (unsigned)__shfl_xor((int)lo, o, 64));
-        hi = max(hi, (unsigned)__shfl_xor((int)hi, o, 64));
+        const unsigned long long l2 = (unsigned long long)__shfl_xor((long long)lo, o, 64);
+        const unsigned long long h2 = (unsigned long long)__shfl_xor((long long)hi, o, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
     }
     if (lane == 0) { red_lo[wave] = lo; red_hi[wave] = hi; }
-    __syncthreads();
+    __syncthreads();                      // also: boff / coarse zeroed
     lo = red_lo[0]; hi = red_hi[0];
 #pragma unroll
-    for (int w = 1; w < SS_WAVES; ++w) { lo = min(lo, red_lo[w]); hi = max(hi, red_hi[w]); }
-    const float scale = (float)nbk / ((float)(hi - lo) + 1.0f);
-    auto sub_bucket = [&](unsigned d) -> int {
-        const int v = (int)((float)(d - lo) * scale);     // monotone in d
-        return min(v, nbk - 1);
+    for (int w = 1; w < SS_WAVES; ++w) {
+        lo = red_lo[w] < lo ? red_lo[w] : lo;
+        hi = red_hi[w] > hi ? red_hi[w] : hi;
+    }
+    const double s1 = (double)SS_NC / ((double)(hi - lo) + 1.0);
+    // key -> (coarse bin, position inside the bin in [0, 1]); monotone in the key
+    auto level1 = [&](unsigned long long K, float& frac) -> int {
+        const double p = (double)(K - lo) * s1;
+        int c = (int)p;
+        c = c < SS_NC - 1 ? c : SS_NC - 1;
+        frac = (float)(p - (double)c);    // p - c is exact; (float) rounds monotonically
+        return c;
+    };
+    // (the bucket of a record is recomputed in every pass rather than kept: ~20 VALU ops against 2 registers per
+    //  record, and the kernel needs <= 80 VGPRs for three workgroups per CU)
+#pragma unroll
+    for (int k = 0; k < SS_RPT; ++k) {
+        if (t + k * SS_THREADS < n) {
+            float frac;
+            atomicAdd(&coarse[level1(rec_key60(rec[k]), frac)], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the coarse counts: thread t owns bin t
+        const unsigned c = coarse[t];              // <= cap <= SS_MAX_CAP: fits 16 bits
+        const unsigned incl = (unsigned)sc_wave_incl_scan((int)c);
+        if (lane == 63) red_sum[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - c;
+#pragma unroll
+        for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
+        coarse[t] = c | (run << 16);
+    }
+    __syncthreads();
+    auto fine_of = [&](unsigned long long K) -> int {
+        float frac;
+        const unsigned cs = coarse[level1(K, frac)];
+        const int cnt = (int)(cs & 0xffffu);
+        int f = (int)(frac * (float)cnt);
+        f = f < cnt - 1 ? f : cnt - 1;
+        return (int)(cs >> 16) + (f > 0 ? f : 0);
     };
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k)
-        if (t + k * SS_THREADS < n) atomicAdd(&boff[sub_bucket(rec[k].x)], 1u);
+        if (t + k * SS_THREADS < n) atomicAdd(&boff[fine_of(rec_key60(rec[k]))], 1u);
     __syncthreads();
-    // exclusive scan: thread t owns per_thread consecutive counters (per_thread is ODD: the
-    // lanes' strides then hit 32 distinct banks instead of two)
-    unsigned sum = 0, occ = 0;
-    for (int k = 0; k < per_thread; ++k) {
-        const unsigned c = boff[t * per_thread + k];
-        sum += c;
-        occ = max(occ, c);
-    }
-    const unsigned incl = (unsigned)sc_wave_incl_scan((int)sum);
+    {   // exclusive scan of the n fine counters: thread t owns `per` consecutive ones (per is ODD: the
+        // lanes' strides then hit 32 distinct banks instead of two)
+        const int per = ((n + SS_THREADS - 1) / SS_THREADS) | 1;
+        const int beg = min(t * per, n), end = min(beg + per, n);
+        unsigned sum = 0;
+        for (int i = beg; i < end; ++i) sum += boff[i];
+        const unsigned incl = (unsigned)sc_wave_incl_scan((int)sum);
+        __syncthreads();                  // red_sum is reused
+        if (lane == 63) red_sum[wave] = incl;
+        __syncthreads();
+        unsigned run = incl - sum;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) occ = max(occ, (unsigned)__shfl_xor((int)occ, o, 64));
-    if (lane == 63) red_sum[wave] = incl;
-    if (lane == 0) red_occ[wave] = occ;
-    __syncthreads();
-    occ = red_occ[0];
-#pragma unroll
-    for (int w = 1; w < SS_WAVES; ++w) occ = max(occ, red_occ[w]);
-    if (occ > BS_MAX_OCC) {                     // workgroup-uniform
-        if (t == 0) needs_radix[sb] = 1;
-        return;
-    }
-    unsigned run = incl - sum;
-#pragma unroll
-    for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
-    for (int k = 0; k < per_thread; ++k) {      // counts -> sub-bucket starts (used as running cursors)
-        const unsigned c = boff[t * per_thread + k];
-        boff[t * per_thread + k] = run;
-        run += c;
+        for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
+        for (int i = beg; i < end; ++i) {      // counts -> bucket starts (used as running cursors)
+            const unsigned c = boff[i];
+            boff[i] = run;
+            run += c;
+        }
     }
     __syncthreads();
-    // scatter: after this pass boff[j] is the END of sub-bucket j (== start of j+1)
+    // scatter: after this pass boff[j] is the END of fine bucket j (== start of j + 1)
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {
         if (t + k * SS_THREADS < n) {
             const uint2 r = rec[k];
-            const unsigned slot = atomicAdd(&boff[sub_bucket(r.x)], 1u);
+            const unsigned slot = atomicAdd(&boff[fine_of(rec_key60(r))], 1u);
             B[slot] = ((unsigned long long)r.x << 32) | r.y;
         }
     }
     __syncthreads();
     if (dbg & 2) return;
-    // rank inside the sub-bucket by (depth bits, flat id) -> order[rank] = position in B
+    // rank inside the fine bucket by (depth bits, flat id) -> order[rank] = position in B.  Consecutive
+    // threads take consecutive positions, i.e. neighbouring buckets: the LDS reads stay close together.
     for (int p = t; p < n; p += SS_THREADS) {
         const unsigned long long key = B[p];
         const unsigned long long kk = key & KEY_MASK;
-        const int j = sub_bucket((unsigned)(key >> 32));
+        const int j = fine_of(((key >> 32) << 28) | (key & ID_MASK));
         const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
         unsigned r = beg;
         for (unsigned q = beg; q < end; ++q) r += ((B[q] & KEY_MASK) < kk) ? 1u : 0u;
         order[r] = (unsigned short)p;
     }
     __syncthreads();
-    emit_tiles<SS_THREADS>(B, order, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, dbg);
-}
-
-// ---- radix fallback for flagged super-tiles --------------------------------------------------------------
-constexpr int TS_THREADS = 256;
-constexpr int TS_WAVES = 4;
-
-__device__ __forceinline__ unsigned long long ts_match(unsigned d, int bits, bool valid) {
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-    }
-    return peers;
-}
-
-// one stable LSD pass over `bits` (<= 8) key bits starting at `shift`: src -> dst, both in LDS
-__device__ __forceinline__ void ts_pass(const unsigned long long* __restrict__ src,
-                                        unsigned long long* __restrict__ dst, int n, int chunk,
-                                        int shift, int bits, unsigned (*h)[256], unsigned* wtot) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const unsigned mask = (1u << bits) - 1u;
-#pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) h[w][t] = 0;
-    __syncthreads();
-    const int wbeg = wave * chunk, wend = min(wbeg + chunk, n);
-    for (int i = wbeg + lane; i < wend; i += 64)
-        atomicAdd(&h[wave][(unsigned)(src[i] >> shift) & mask], 1u);
-    __syncthreads();
-    {
-        unsigned c[TS_WAVES], tot = 0;
-#pragma unroll
-        for (int w = 0; w < TS_WAVES; ++w) { c[w] = h[w][t]; tot += c[w]; }
-        const unsigned incl = (unsigned)sc_wave_incl_scan((int)tot);
-        if (lane == 63) wtot[wave] = incl;
+    emit_tiles<SS_THREADS>(B, order, n, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tb, table, isect_ids,
+                           flatten_ids, totals, dbg);
+    if (totals_out) {
         __syncthreads();
-        unsigned run = incl - tot;
-#pragma unroll
-        for (int w = 0; w < TS_WAVES; ++w) if (w < wave) run += wtot[w];
-#pragma unroll
-        for (int w = 0; w < TS_WAVES; ++w) { h[w][t] = run; run += c[w]; }
+        if (t < 4) totals_out[t] = totals[t];
     }
-    __syncthreads();
-    for (int i0 = wbeg; i0 < wend; i0 += 64) {
-        const int i = i0 + lane;
-        const bool valid = i < wend;
-        const unsigned long long k = valid ? src[i] : 0ull;
-        const unsigned d = (unsigned)(k >> shift) & mask;
-        const unsigned long long peers = ts_match(d, bits, valid);
-        const unsigned rank = (unsigned)__popcll(peers & sc_lanemask_lt());
-        unsigned pos = 0;
-        if (valid) pos = h[wave][d] + rank;
-        if (valid && rank == 0) h[wave][d] += (unsigned)__popcll(peers);
-        if (valid) dst[pos] = k;
-    }
-    __syncthreads();
 }
 
-// Persistent-style grid: every workgroup strides over the super-tiles and sorts only the flagged
-// ones (normally none: the launch then costs a few hundred flag reads).
-__global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
-    const uint2* __restrict__ records, const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
-    Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
-    int64_t rec_capacity, int64_t super_capacity, int tile_bits, int id_bits, int cap,
-    const unsigned char* __restrict__ needs_radix, int64_t* __restrict__ isect_ids,
-    int32_t* __restrict__ flatten_ids) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long* A = reinterpret_cast<unsigned long long*>(smem);
-    unsigned long long* Bb = A + cap;
-    unsigned long long* table = Bb + cap;
-    __shared__ unsigned h[TS_WAVES][256];
-    __shared__ unsigned wtot[TS_WAVES];
-    __shared__ unsigned diff_s;
-    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
+// Oversized segment whose keys could not be split by depth (a heavy histogram bin: thousands of records within
+// 1/1024 of the super-tile's key range): exact, slow.  Rank every record among all n by counting smaller keys
+// straight from global memory, scatter into `dst` (the super-tile's original bucket, free by now), then emit
+// chunk by chunk through LDS with running per-tile bases.
+__device__ __forceinline__ void sort_heavy_segment(
+    const uint2* __restrict__ src, uint2* __restrict__ dst, int n, int sb, const int* tb_in, int cap, const Geo& g,
+    const int32_t* __restrict__ offsets, int n_tbuckets, int64_t n_isects, int tile_bits, unsigned char* smem,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(smem + (size_t)cap * 8);
+    __shared__ unsigned tot[4];
+    __shared__ int tbr[4];
     const int t = threadIdx.x;
+    for (int i = t; i < n; i += SS_THREADS) {
+        const uint2 r = src[i];
+        const unsigned long long K = rec_key60(r);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += rec_key60(src[j]) < K ? 1 : 0;
+        dst[rank] = r;
+    }
+    if (t < 4) tbr[t] = tb_in[t];
+    __threadfence();
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += cap) {
+        const int m = min(cap, n - c0);
+        for (int i = t; i < m; i += SS_THREADS) {
+            // (agent-scope load: bypasses this CU's L1, which may hold a line of `dst` from before the scatter)
+            const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(dst + c0 + i),
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            B[i] = (v << 32) | (v >> 32);           // uint2 {x = depth, y = mask | id} is x in the low word
+        }
+        __syncthreads();
+        int tbl[4] = {tbr[0], tbr[1], tbr[2], tbr[3]};
+        emit_tiles<SS_THREADS>(B, nullptr, m, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tbl, table, isect_ids,
+                               flatten_ids, tot, 0);
+        __syncthreads();
+        if (t < 4) tbr[t] += (int)tot[t];
+        __syncthreads();
+    }
+}
+
+// One launch sorts everything: blocks [0, seg_bound) take the segments big_split_kernel produced (none in the
+// common case: those blocks return at once), blocks [seg_bound, seg_bound + n_sbuckets) the super-tiles whose
+// bucket fits the LDS capacity.
+__global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
+    const uint2* __restrict__ records, uint2* __restrict__ records_rw, const uint2* __restrict__ temp,
+    const Segment* __restrict__ segs, const unsigned* __restrict__ n_segs, int seg_bound,
+    const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
+    Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
+    int64_t rec_capacity, int64_t super_capacity, int tile_bits, int cap,
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    // the SAME three comparisons in every kernel of the sort phase and in the host wrapper
+    // (rendering._bin_launch_ran): a launch either runs in full or not at all
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
+    __shared__ int tb_s[4];
+    if ((int)blockIdx.x < seg_bound) {
+        if (blockIdx.x >= *n_segs) return;
+        const Segment* sg = segs + blockIdx.x;
+        if (threadIdx.x < 4) tb_s[threadIdx.x] = sg->tb[threadIdx.x];
+        const int start = sg->start, sn = sg->n, ssb = sg->sb;
+        __syncthreads();
+        if (sg->heavy)
+            sort_heavy_segment(temp + start, records_rw + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets,
+                               meta[0], tile_bits, smem, isect_ids, flatten_ids);
+        else
+            sort_segment(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem,
+                         isect_ids, flatten_ids, nullptr, dbg);
+        return;
+    }
+    const int sb = (int)blockIdx.x - seg_bound;
+    const int s = soffsets[sb];
+    const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
+    const int n = e - s;
+    if (n <= 0 || n > cap) return;          // n > cap: big_split_kernel has cut this bucket into segments
+    if (threadIdx.x < 4) tb_s[threadIdx.x] = 0;
+    __syncthreads();
+    sort_segment(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
+                 flatten_ids, nullptr, dbg);
+}
+
+// ---- oversized buckets: cut into depth ranges that fit the LDS sort ---------------------------------------
+// One workgroup per oversized super-tile (n > cap records; grid-stride over the super-tiles):
+//   1. min / max of the 60-bit key; histogram of the records over BS_NB bins of a monotone linear map;
+//   2. consecutive bins are grouped into RANGES of at most cap records (greedy on the prefix sums; a bin
+//      that alone exceeds cap / 2 becomes a range of its own, `heavy` if it exceeds cap);
+//   3. the records are copied into `temp` grouped by range (order inside a range is arbitrary: the segment
+//      sort fixes it), with, per range, the number of its records in each of the 4 tiles -- their prefix
+//      sums are the tile bases the range's workgroup adds when it emits;
+//   4. one Segment per range.
+constexpr int BS_THREADS = 1024;
+constexpr int BS_NB = 1024;                       // histogram bins == threads
+constexpr int BS_MAX_RANGES = 256;                // ranges one oversized bucket may be cut into (LDS tables)
+constexpr int BS_UNROLL = 8;                      // records a thread has in flight per step (the passes are latency-bound)
+
+// f(record, valid) over the n records at `src`, BS_UNROLL independent loads per thread in flight
+template <typename F>
+__device__ __forceinline__ void for_records(const uint2* __restrict__ src, int n, F&& f) {
+    for (int i0 = threadIdx.x; i0 < n; i0 += BS_THREADS * BS_UNROLL) {
+        uint2 v[BS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BS_UNROLL; ++u) {
+            const int i = i0 + u * BS_THREADS;
+            v[u] = i < n ? src[i] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < BS_UNROLL; ++u)
+            if (i0 + u * BS_THREADS < n) f(v[u]);
+    }
+}
+
+__global__ __launch_bounds__(BS_THREADS) void big_split_kernel(
+    const uint2* __restrict__ records, uint2* __restrict__ temp, Segment* __restrict__ segs,
+    unsigned* __restrict__ n_segs, int seg_bound, const int32_t* __restrict__ soffsets, int n_sbuckets,
+    const int64_t* __restrict__ meta, int64_t capacity, int64_t rec_capacity, int64_t super_capacity, int cap,
+    int dbg) {
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
+    // The keys of a street-scene bucket sit in a few narrow depth bands, so many lanes of a wave hit the SAME
+    // few counters and an LDS atomic instruction serialises identical addresses: every bin counter has 8
+    // replicas picked by lane & 7, the per-range tile counters 4.  (Measured on the street scene, 1 M Gaussians,
+    // ~6 M of 8.8 M records in oversized buckets: the kernel takes ~100 us whatever the counters look like --
+    // it is three latency-bound passes over the buckets, one workgroup each; wave-aggregated adds with ballots
+    // instead of per-lane atomics made the copy pass 6x slower.)
+    constexpr int REP = 8;
+    __shared__ unsigned hist[BS_NB * REP];         // replicated bin counts; hist[b * REP] later: range of bin b
+    constexpr int TREP = 4;
+    __shared__ unsigned rcnt[BS_MAX_RANGES], rtile[BS_MAX_RANGES][4][TREP], rstart[BS_MAX_RANGES], rcur[BS_MAX_RANGES];
+    __shared__ unsigned long long red_lo[BS_THREADS / 64], red_hi[BS_THREADS / 64];
+    __shared__ unsigned wtot[BS_THREADS / 64], wheavy[BS_THREADS / 64];
+    __shared__ unsigned n_ranges_s, seg_base_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int target = cap / 2;
     for (int sb = blockIdx.x; sb < n_sbuckets; sb += gridDim.x) {
-        if (!needs_radix[sb]) continue;              // workgroup-uniform
         const int s = soffsets[sb];
         const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
         const int n = e - s;
-        if (n <= 0) continue;
+        if (n <= cap) continue;                    // workgroup-uniform
+        const uint2* src = records + s;
         __syncthreads();
-        if (t == 0) diff_s = 0;
-        __syncthreads();
-        const unsigned first_depth = records[s].x;
-        unsigned diff = 0;
-        for (int i = t; i < n; i += TS_THREADS) {
-            const uint2 r = records[s + i];
-            A[i] = ((unsigned long long)r.x << 32) | r.y;
-            diff |= r.x ^ first_depth;
-        }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) diff |= (unsigned)__shfl_xor((int)diff, o, 64);
-        if ((t & 63) == 0 && diff) atomicOr(&diff_s, diff);
+        for (int k = 0; k < REP; ++k) hist[t * REP + k] = 0;
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for_records(src, n, [&](uint2 rc) {
+            const unsigned long long K = rec_key60(rc);
+            lo = K < lo ? K : lo;
+            hi = K > hi ? K : hi;
+        });
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned long long l2 = (unsigned long long)__shfl_xor((long long)lo, o, 64);
+            const unsigned long long h2 = (unsigned long long)__shfl_xor((long long)hi, o, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) { red_lo[wave] = lo; red_hi[wave] = hi; }
         __syncthreads();
-        const int sig = 32 - __clz((int)diff_s);      // significant depth bits (0 when all equal)
-        int chunk = (n + TS_WAVES - 1) / TS_WAVES;
-        chunk = (chunk + 63) & ~63;
-        unsigned long long* src = A;
-        unsigned long long* dst = Bb;
-        // LSD on the full (depth, id) key: id bits first (bits 28..31 hold the tile mask and are
-        // skipped), then the significant depth bits
-        for (int done = 0; done < id_bits;) {
-            const int bits = min(8, id_bits - done);
-            ts_pass(src, dst, n, chunk, done, bits, h, wtot);
-            unsigned long long* tmp = src; src = dst; dst = tmp;
-            done += bits;
+        lo = red_lo[0]; hi = red_hi[0];
+        for (int w = 1; w < BS_THREADS / 64; ++w) {
+            lo = red_lo[w] < lo ? red_lo[w] : lo;
+            hi = red_hi[w] > hi ? red_hi[w] : hi;
         }
-        for (int done = 0; done < sig;) {
-            const int bits = min(8, sig - done);
-            ts_pass(src, dst, n, chunk, 32 + done, bits, h, wtot);
-            unsigned long long* tmp = src; src = dst; dst = tmp;
-            done += bits;
+        const double sc = (double)BS_NB / ((double)(hi - lo) + 1.0);
+        auto bin_of = [&](unsigned long long K) -> int {
+            const int b = (int)((double)(K - lo) * sc);
+            return b < BS_NB - 1 ? b : BS_NB - 1;
+        };
+        for_records(src, n, [&](uint2 rc) { atomicAdd(&hist[bin_of(rec_key60(rc)) * REP + (lane & (REP - 1))], 1u); });
+        __syncthreads();
+        // thread t owns bin t.  light = exclusive prefix of the light bins' counts, H = heavy bins before t.
+        unsigned c = 0;
+#pragma unroll
+        for (int k = 0; k < REP; ++k) c += hist[t * REP + k];
+        const bool heavy = c > (unsigned)target;
+        const unsigned lc = heavy ? 0u : c;
+        const unsigned incl = (unsigned)sc_wave_incl_scan((int)lc);
+        const unsigned hincl = (unsigned)sc_wave_incl_scan(heavy ? 1 : 0);
+        if (lane == 63) { wtot[wave] = incl; wheavy[wave] = hincl; }
+        __syncthreads();
+        unsigned light = incl - lc, H = hincl - (heavy ? 1u : 0u);
+        for (int w = 0; w < BS_THREADS / 64; ++w)
+            if (w < wave) { light += wtot[w]; H += wheavy[w]; }
+        // sparse, monotone range id: light bins floor(light / target) + 2 H, a heavy bin the odd id after them
+        const unsigned rid = light / (unsigned)target + 2u * H + (heavy ? 1u : 0u);
+        // dense id = number of distinct rids among the non-empty bins up to this one, minus one.
+        // The rid of the nearest non-empty bin to the LEFT comes from a running-maximum scan (rids are
+        // monotone in the bin index; a serial walk over the mostly empty histogram cost tens of microseconds).
+        const int mine = c ? (int)rid : -1;
+        int run_max = mine;                        // inclusive running maximum inside the wave
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int o = __shfl_up(run_max, dlt, 64);
+            if (lane >= dlt) run_max = max(run_max, o);
         }
-        emit_tiles<TS_THREADS>(src, nullptr, n, sb, g, offsets, n_tbuckets, meta[0], tile_bits, table, isect_ids, flatten_ids, 0);
+        int left = __shfl_up(run_max, 1, 64);      // exclusive: bins to the left inside the wave
+        if (lane == 0) left = -1;
+        __syncthreads();
+        if (lane == 63) wheavy[wave] = (unsigned)(run_max + 1);     // (+1: stored unsigned, -1 -> 0)
+        __syncthreads();
+        for (int w = 0; w < BS_THREADS / 64; ++w)
+            if (w < wave) left = max(left, (int)wheavy[w] - 1);
+        const bool first = c && left != (int)rid;
+        const unsigned fincl = (unsigned)sc_wave_incl_scan(first ? 1 : 0);
+        __syncthreads();
+        if (lane == 63) wtot[wave] = fincl;
+        for (int r = t; r < BS_MAX_RANGES; r += BS_THREADS) {
+            rcnt[r] = 0; rcur[r] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < TREP; ++q) rtile[r][k][q] = 0;
+        }
+        __syncthreads();
+        unsigned dense = fincl;
+        unsigned total_ranges = 0;
+        for (int w = 0; w < BS_THREADS / 64; ++w) {
+            if (w < wave) dense += wtot[w];
+            total_ranges += wtot[w];
+        }
+        dense -= 1u;                                // this bin's range (meaningless for empty bins)
+        hist[t * REP] = c ? dense : 0u;             // bin -> range
+        if (t == 0) n_ranges_s = total_ranges;
+        if (c) atomicAdd(&rcnt[dense], c);          // range totals from the bin totals
+        __syncthreads();
+        const int R = (int)n_ranges_s;             // <= 2 n / target + 1 <= BS_MAX_RANGES (the host bounds n)
+        if (t == 0) {                               // R is small: serial prefix sum
+            unsigned run = 0;
+            for (int r = 0; r < R; ++r) { rstart[r] = run; run += rcnt[r]; }
+            seg_base_s = atomicAdd(n_segs, (unsigned)R);
+        }
+        __syncthreads();
+        // copy pass: records grouped by range; per range, how many of its records fall in each of the 4 tiles
+        // (replicated counters again: a range's records are many lanes of every wave)
+        uint2* dst = temp + s;
+        if (!(dbg & 4))        // diagnostic: skip the copy pass (segments then hold stale records; every consumer bounds-checks)
+        for_records(src, n, [&](uint2 rc) {
+            const unsigned r = hist[bin_of(rec_key60(rc)) * REP];
+            const unsigned slot = rstart[r] + atomicAdd(&rcur[r], 1u);
+            const unsigned m = rc.y >> 28;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((m >> k) & 1u) atomicAdd(&rtile[r][k][lane & (TREP - 1)], 1u);
+            if (slot < (unsigned)n) dst[slot] = rc;      // (slot < n by construction; never trust it)
+        });
+        __syncthreads();
+        if (t == 0) {                               // per-tile counts -> exclusive prefix over the ranges
+            unsigned tr[4] = {0, 0, 0, 0};
+            for (int r = 0; r < R; ++r) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    unsigned v = 0;
+#pragma unroll
+                    for (int q = 0; q < TREP; ++q) v += rtile[r][k][q];
+                    rtile[r][k][0] = tr[k];
+                    tr[k] += v;
+                }
+            }
+        }
+        __syncthreads();
+        const unsigned base = seg_base_s;
+        for (int r = t; r < R; r += BS_THREADS) {
+            if (base + r < (unsigned)seg_bound) {
+                Segment sg;
+                sg.start = s + (int)rstart[r]; sg.n = (int)rcnt[r]; sg.sb = sb; sg.heavy = (int)rcnt[r] > cap ? 1 : 0;
+                sg.tb[0] = (int)rtile[r][0][0]; sg.tb[1] = (int)rtile[r][1][0];
+                sg.tb[2] = (int)rtile[r][2][0]; sg.tb[3] = (int)rtile[r][3][0];
+                segs[base + r] = sg;
+            }
+        }
     }
 }
 
@@ -775,16 +983,17 @@ __global__ __launch_bounds__(TS_THREADS) void super_radix_kernel(
 
 // ---- host side --------------------------------------------------------------------------------
 // count-phase workspace (handed to BOTH calls):
-//   dgrid_t | dgrid_s | chist | ccursor | rcursor | rflags | scans_done | soffsets | cstart | smeta[2] | cmeta[2] | sorted uint4[CN]
-//   (everything before soffsets is zeroed by the ONE memset of a frame; rcursor / rflags are the
-//    scatter's bucket cursors and the "needs the radix fallback" flags of the sort phase, kept here so
-//    that the sort phase needs no memset of its own: a second memset cost 5 us + a 6 us bubble)
+//   dgrid_t | dgrid_s | chist | ccursor | rcursor | nseg | scans_done | soffsets | cstart | smeta[2] | cmeta[2] | sorted uint4[CN]
+//   (everything before soffsets is zeroed by the ONE memset of a frame; rcursor / nseg are the
+//    scatter's bucket cursors and the segment counter of the sort phase, kept here so that the sort
+//    phase needs no memset of its own: a second memset cost 5 us + a 6 us bubble)
 // sort-phase workspace:
-//   records uint2[rec_capacity]
+//   records uint2[rec_capacity] | (only when oversized buckets are provisioned for) temp uint2[rec_capacity] |
+//   segments[seg_bound]
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
-    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, rflags, scans_done, soffsets, cstart, smeta, cmeta, sorted, total;
+    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, nseg, scans_done, soffsets, cstart, smeta, cmeta, sorted, total;
 };
 
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
@@ -805,7 +1014,7 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.chist = take((size_t)L.nsb * 4);
     L.ccursor = take((size_t)L.nsb * 4);
     L.rcursor = take((size_t)L.nsb * 4);
-    L.rflags = take((size_t)L.nsb);
+    L.nseg = take(4);
     L.scans_done = take(4);
     L.soffsets = take((size_t)L.nsb * 4);
     L.cstart = take((size_t)L.nsb * 4);
@@ -831,11 +1040,14 @@ static hipError_t bin_attrs_once() {
     const int a = hipFuncAttributeMaxDynamicSharedMemorySize;
     if ((e = hipFuncSetAttribute((const void*)bin_count_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
-    // (super_sort_kernel also has ~4 KiB of static LDS: stay below 160 KiB in total)
-    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 156 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)super_radix_kernel, (hipFuncAttribute)a, 150 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
     done[dev] = true;
     return hipSuccess;
+}
+
+// upper bound of the segments big_split_kernel can produce: 2 n / (cap / 2) + 1 per oversized bucket
+static inline size_t seg_bound_for(int64_t n_records, int nsb) {
+    return (size_t)(2 * (n_records > 0 ? n_records : 0) / (SS_MAX_CAP / 2)) + (size_t)nsb + 8;
 }
 
 static inline size_t count_lds_bytes(const BinLayout& L) {
@@ -848,7 +1060,9 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
     if (nb <= 0 || nb > BIN_MAX_TILES) return 256;
     const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
     if (n_isects < 0) return L.total;                                  // count-phase workspace
-    return sc_align_up((size_t)n_isects * 8, 256) + 256;
+    // records + (for the split path) a second copy + the segment list; the wrapper cannot know here whether
+    // oversized buckets will occur, so the size covers them: the extra bytes are only touched when they do
+    return 2 * sc_align_up((size_t)n_isects * 8, 256) + sc_align_up(seg_bound_for(n_isects, L.nsb) * sizeof(Segment), 256) + 256;
 }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
@@ -915,7 +1129,7 @@ extern "C" int sc_isect_bin_reset_cursors(void* count_workspace, int64_t CN, int
     if (!count_workspace || C <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if ((int64_t)C * tile_width * tile_height > BIN_MAX_TILES) return SC_EUNSUPPORTED;
     const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
-    SC_HIP(hipMemsetAsync((unsigned char*)count_workspace + L.rcursor, 0, L.scans_done - L.rcursor, sc_s(stream)));
+    SC_HIP(hipMemsetAsync((unsigned char*)count_workspace + L.rcursor, 0, L.scans_done - L.rcursor, sc_s(stream)));   // rcursor + nseg
     return SC_OK;
 }
 
@@ -932,9 +1146,11 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     const int64_t nb64 = (int64_t)C * tile_width * tile_height;
     if (nb64 > BIN_MAX_TILES || CN >= (1LL << 28) || capacity > 0x7fffffffLL) return SC_EUNSUPPORTED;
     if (capacity == 0 || CN == 0) return SC_OK;
-    // LDS of one super-tile workgroup: 20 B per record (+ table) must fit ~150 KiB
-    if (super_capacity > SS_MAX_CAP) return SC_EUNSUPPORTED;
-    int cap = (int)((super_capacity + 255) / 256 * 256);
+    // Buckets of up to SS_MAX_CAP records are sorted by one workgroup in LDS; when the caller provisions for
+    // larger ones (super_capacity > SS_MAX_CAP) they are first cut into depth ranges (big_split_kernel).
+    if (super_capacity > BIG_MAX_SUPER) return SC_EUNSUPPORTED;
+    const bool big = super_capacity > SS_MAX_CAP;
+    int cap = big ? SS_MAX_CAP : (int)((super_capacity + 255) / 256 * 256);
     if (cap < 256) cap = 256;
     if (!means2d || !radii || !depths || !isect_offsets || !meta_dev || !count_workspace || !flatten_ids ||
         !workspace)
@@ -949,33 +1165,28 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     // zero since sc_isect_bin_count; consumed by the one launch whose capacities pass the device-side
     // check (kernels of a launch with too small capacities return before touching them)
     unsigned* cursor = (unsigned*)(cws + L.rcursor);
-    unsigned char* needs_radix = cws + L.rflags;
+    unsigned* n_segs = (unsigned*)(cws + L.nseg);
+    const size_t rec_bytes = sc_align_up((size_t)rec_capacity * 8, 256);
     uint2* records = (uint2*)workspace;
+    uint2* temp = (uint2*)((unsigned char*)workspace + rec_bytes);
+    Segment* segs = (Segment*)((unsigned char*)workspace + 2 * rec_bytes);
+    const int seg_bound = big ? (int)seg_bound_for(rec_capacity, L.nsb) : 0;
     hipLaunchKernelGGL(bin_scatter_flat_kernel, dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
                        dim3(FLAT_THREADS), (size_t)L.nsb * 8 + FLAT_WAVES * sizeof(FlatTab), s, sorted, cmeta, L.g, L.nsb,
                        soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records, g_sc_debug[0]);
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
-    const int id_bits = sc_bits_for(CN > 1 ? CN - 1 : 1);
-    // sub-buckets per thread: ~1 per record (keeps two workgroups resident per CU), rounded up to
-    // an ODD count (bank-conflict-free scan)
-    int per_thread = (cap + SS_THREADS - 1) / SS_THREADS;
-    per_thread |= 1;
-    const int nbk = SS_THREADS * per_thread;
-    const size_t table_bytes = (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64;
-    const size_t lds_sort = (size_t)cap * 10 + (size_t)((nbk + 2) & ~1) * 4 + table_bytes;
-    const size_t table_radix = (size_t)((cap + TS_THREADS - 1) / TS_THREADS + 1) * TS_WAVES * 8 + 64;
-    const size_t lds_radix = (size_t)cap * 16 + table_radix;
-    if (lds_sort > 156 * 1024) return SC_EUNSUPPORTED;
     SC_HIP(bin_attrs_once());
-    hipLaunchKernelGGL(super_sort_kernel, dim3(L.nsb), dim3(SS_THREADS), lds_sort, s, (const uint2*)records, soffsets,
-                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, super_capacity, tile_bits, cap,
-                       per_thread, needs_radix, isect_ids, flatten_ids, g_sc_debug[2]);
-    SC_LAUNCH_CHECK();
-    const int rgrid = L.nsb < 512 ? L.nsb : 512;      // persistent; A/B when no super-tile is flagged: 128 -> 8.5 us, 512 -> 4.8 us
-    hipLaunchKernelGGL(super_radix_kernel, dim3(rgrid), dim3(TS_THREADS), lds_radix, s, (const uint2*)records, soffsets,
-                       L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, super_capacity, tile_bits, id_bits,
-                       cap, (const unsigned char*)needs_radix, isect_ids, flatten_ids);
+    if (big) {
+        const int bgrid = L.nsb;          // one workgroup per super-tile: the hardware balances the oversized ones
+        hipLaunchKernelGGL(big_split_kernel, dim3(bgrid), dim3(BS_THREADS), 0, s, (const uint2*)records, temp, segs,
+                           n_segs, seg_bound, soffsets, L.nsb, meta_dev, capacity, rec_capacity, super_capacity, cap, g_sc_debug[3]);
+        SC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(super_sort_kernel, dim3((unsigned)(seg_bound + L.nsb)), dim3(SS_THREADS), sort_lds_bytes(cap), s,
+                       (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
+                       (const unsigned*)n_segs, seg_bound, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
+                       capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids, g_sc_debug[2]);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -322,7 +322,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     _BIN_LAST_META[key] = (n_isects, n_records, max_super)
     # next call: 12.5 % head-room over what this frame needed
     _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, n_records + n_records // 8 + 4096,
-                            min(7168, max_super + max_super // 8 + 64))
+                            max_super + max_super // 8 + 64)
     flatten_ids = fids[:n_isects]
     isect_ids = None
     if want_ids:

@@ -178,25 +178,81 @@ def test_isect_depth_ties_keep_index_order(ops, mode, n_depths):
     np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, tw, th))
 
 
-def test_isect_bin_falls_back_when_a_super_tile_overflows_lds(ops):
-    """> 7168 records in one 2x2 super-tile: the bucketed path reports SC_EUNSUPPORTED and the
-    wrapper must take the count/emit/radix route -- same bit-exact result."""
+def _isect_both_routes(ops, m2, r, d, tw, th, C=1):
+    from street_crafter_amd import rendering
+    out = {}
+    for mode in ("radix", "bin"):
+        prev = rendering.set_isect_mode(mode)
+        try:
+            tpg, ids, fids = ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=C)
+            out[mode] = (tpg, ids, fids, ops.isect_offset_encode(ids, C, tw, th))
+        finally:
+            rendering.set_isect_mode(prev)
+    return out
+
+
+@pytest.mark.parametrize("shape", ["uniform", "cluster_and_outliers", "equal_depths", "heavy_bin", "two_heavy_bins"])
+def test_isect_bin_oversized_super_tiles_are_split_not_abandoned(ops, shape):
+    """A super-tile with more records than one workgroup sorts in LDS (3584) used to send the WHOLE frame down
+    the radix route (11x slower).  Now only that bucket is cut into depth ranges (big_split_kernel)
+    and the ranges are sorted like ordinary buckets; a range that cannot be cut by depth (thousands of records
+    within 1/1024 of the key range: 'heavy') takes an exact quadratic path.  Every shape must reproduce the
+    oracle bit for bit and stay on the bucketed route."""
+    from street_crafter_amd import rendering
     rng = np.random.default_rng(5)
-    N = 20000
-    m2 = rng.uniform(0, 32, size=(1, N, 2)).astype(np.float32)          # everything inside one super-tile
+    N = 30000
+    m2 = rng.uniform(0, 32, size=(1, N, 2)).astype(np.float32)          # everything inside one super-tile ...
+    m2[0, :3000] = rng.uniform(0, 96, size=(3000, 2))                    # ... and some ordinary neighbours
     r = rng.integers(1, 6, size=(1, N)).astype(np.int32)
     d = rng.uniform(1.0, 50.0, size=(1, N)).astype(np.float32)
-    e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 6, 4)
-    tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 6, 4)
-    off = ops.isect_offset_encode(ids, 1, 6, 4)
-    np.testing.assert_array_equal(_np(tpg), e_tpg)
-    np.testing.assert_array_equal(_np(ids), e_ids)
-    np.testing.assert_array_equal(_np(fids), e_f)
-    np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, 6, 4))
+    if shape == "cluster_and_outliers":       # a facade (narrow cluster) + sky (far outliers)
+        d[0, :24000] = rng.uniform(30.0, 30.1, size=24000)
+        d[0, 24000:24100] = rng.uniform(200.0, 900.0, size=100)
+    elif shape == "equal_depths":             # ties: only the flat id orders them
+        d[0, :20000] = 7.5
+    elif shape == "heavy_bin":                # 12000 records inside one histogram bin of the split
+        d[0, :12000] = np.float32(10.0) + rng.integers(0, 3, size=12000).astype(np.float32) * np.float32(1e-6)
+        d[0, 12000:12050] = rng.uniform(500.0, 1000.0, size=50)
+    elif shape == "two_heavy_bins":
+        d[0, :9000] = 10.0
+        d[0, 9000:18000] = np.float32(10.000001)
+        d[0, 18000:18010] = 900.0
+    e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 6, 6)
+    key = (torch.cuda.current_device(), 1, N, 16, 6, 6)
+    rendering._BIN_LAST_META.pop(key, None)
+    rendering._BIN_PREDICTION.pop(key, None)
+    for _ in range(2):                        # second call: sizes predicted from the first
+        tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 6, 6)
+        off = ops.isect_offset_encode(ids, 1, 6, 6)
+        np.testing.assert_array_equal(_np(tpg), e_tpg)
+        np.testing.assert_array_equal(_np(ids), e_ids)
+        np.testing.assert_array_equal(_np(fids), e_f)
+        np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, 6, 6))
+    assert rendering._BIN_LAST_META[key][2] > 20000           # the bucketed route ran, with a 20k+ bucket
+
+
+def test_isect_bin_street_scene_matches_the_radix_route(ops):
+    """The street-shaped scene (dense horizon band: hundreds of oversized super-tiles; sky splats hundreds of
+    pixels wide: rectangles of hundreds of tiles) through both routes at full resolution: bit-identical."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.scenes import make_street_scene
+    for scene in make_street_scene(400_000, n_sky=12_000, seed=11):
+        cam = make_camera()
+        with torch.no_grad():
+            r, m2, d, _, _ = ops.fully_fused_projection(scene.means.to(DEV), None, scene.quats.to(DEV), scene.scales.to(DEV),
+                                                        cam.viewmat.to(DEV)[None], cam.K.to(DEV)[None], 1920, 1280,
+                                                        near_plane=0.001, far_plane=1000.0)
+        key = (torch.cuda.current_device(), 1, scene.n, 16, 120, 80)
+        rendering._BIN_LAST_META.pop(key, None)
+        out = _isect_both_routes(ops, m2, r, d, 120, 80)
+        for a, b in zip(out["bin"], out["radix"]):
+            assert torch.equal(a, b)
+        assert key in rendering._BIN_LAST_META                 # the bucketed route took it
+    assert rendering._BIN_LAST_META[(torch.cuda.current_device(), 1, 400_000, 16, 120, 80)][2] > 3584
 
 
 @pytest.mark.parametrize("how", ["super_just_below", "super_rounding_window", "isects_too_small", "records_too_small",
-                                 "all_too_small", "generous"])
+                                 "all_too_small", "generous", "provisioned_for_split"])
 def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
     """The scatter + sort are enqueued with capacities predicted from the previous frame and verified on the
     device; a wrong prediction must end in ONE full run with exact sizes (a launch that passed the
@@ -228,10 +284,11 @@ def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
         "super_just_below": (big, big, max_super - 1),
         # old bug: host compared with the unrounded number, device with the value rounded up to 256
         "super_rounding_window": (big, big, min(window, max_super - 1)),
-        "isects_too_small": (n_is - 1, big, 7168),
-        "records_too_small": (big, max(1, n_rec // 2), 7168),
+        "isects_too_small": (n_is - 1, big, big),
+        "records_too_small": (big, max(1, n_rec // 2), big),
         "all_too_small": (1, 1, 1),
-        "generous": (big, big, 7168),
+        "generous": (big, big, max_super + 100),
+        "provisioned_for_split": (big, big, 200_000),        # the split kernels launch and find nothing to do
     }
     pred = seeds[how]
     if how == "super_rounding_window":

@@ -1,7 +1,7 @@
 """A/B timing of kernel variants / diagnostic skips on S-1M, interleaved in ONE process
 (guide rule 24).  Prints per-operator HIP-event times per configuration.
 
-    python tools/exp_kernels.py [n_gauss] [rounds]
+    python tools/exp_kernels.py [n_gauss] [rounds] [street]
 """
 import os
 import sys
@@ -13,12 +13,13 @@ import torch  # noqa: E402
 
 from street_crafter_amd import _lib, rendering  # noqa: E402
 from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
-from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
+from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+STREET = len(sys.argv) > 3 and sys.argv[3] == "street"
 dev = "cuda"
-scene = make_scene(N).to(dev)
+scene = (make_street_scene(N)[0] if STREET else make_scene(N)).to(dev)
 cam = make_camera().to(dev)
 
 CONFIGS = [
@@ -28,6 +29,7 @@ CONFIGS = [
     ("raster: no blend loop", {"debug1": 1}),
     ("bucket sort: no final stores", {"debug2": 1}),
     ("bucket sort: no rank loop/stores", {"debug2": 2}),
+    ("split: no copy pass", {"debug3": 4}),
     ("isect radix route", {"isect": "radix"}),
     ("raster variant 0", {"raster_fwd": 0}),
     ("raster variant 3", {"raster_fwd": 3}),

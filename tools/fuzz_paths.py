@@ -13,7 +13,7 @@ import torch  # noqa: E402
 
 import gsplat.rendering as R  # noqa: E402
 from street_crafter_amd import _lib, rendering  # noqa: E402
-from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
+from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -29,7 +29,11 @@ for it in range(ROUNDS):
     deg = int(rng.integers(0, 4))
     sc = make_scene(n, sh_degree=deg, seed=int(rng.integers(1 << 30)), z_range=(zmin, zmin * float(rng.choice([2, 40]))),
                     scale_range=(0.004, smax)).to("cuda")
-    if rng.random() < 0.3 and n > 10:          # many equal depths: exercises the radix fallback of the sort
+    if rng.random() < 0.3 and n > 1000:        # street-shaped instead of i.i.d.: oversized super-tiles, huge splats
+        fg, sky = make_street_scene(n, n_sky=max(8, n // 20), sh_degree=deg, seed=int(rng.integers(1 << 30)))
+        sc = (fg if rng.random() < 0.7 else sky).to("cuda")
+        n = sc.n
+    if rng.random() < 0.3 and n > 10:          # many equal depths: only the id bits of the sort key separate them
         sc.means[:, 2] = torch.round(sc.means[:, 2])
     f = 2050.0 * W / 1920.0
     cams = [make_camera(W, H, f, f, yaw=0.05 * i, shift=(0.2 * i, 0.0, 0.0)) for i in range(C)]

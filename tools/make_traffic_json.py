@@ -11,7 +11,7 @@ from collections import defaultdict
 OPS = {
     "projection": ["projection_fwd_kernel"],
     "isect_tiles": ["bin_count_kernel", "center_scatter_kernel",
-                    "bin_scatter_flat_kernel", "super_sort_kernel", "super_radix_kernel"],
+                    "bin_scatter_flat_kernel", "big_split_kernel", "super_sort_kernel"],
     "spherical_harmonics": ["sh_fwd_kernel"],
     "rasterize_to_pixels": ["raster_fwd_wave_kernel", "raster_fwd_ref_kernel"],
 }
