@@ -8,14 +8,17 @@ is a third-party CUDA extension (requirements.txt:39) that is not in /root/refer
 installed; the reference holds no output image or test for this path.  What IS contractual and is
 reproduced here: the frame assembly (which points, in which frame, under which poses), the visibility
 filter, the point radius rule (`use_ndc_scale`, render_utils.py:116-122: a constant SCREEN-space radius
-of scale * 0.5 * min(H, W) pixels), `max_hit = 10` front-most hits per pixel (:160), opacity `occ`,
+of scale * 0.5 * min(H, W) pixels; `use_knn_scale`, :123-127: world radius from the local point density
+through simple_knn.distCUDA2 -- the LiDAR path's one consumer of SURVEY row a14 -- capped by `scale`),
+`max_hit = 10` front-most hits per pixel (:160), opacity `occ`,
 black background, and the output layout `[1, H, W, 4]` = rgb + accumulated alpha (:179-183).  The
 splat footprint is taken as a hard disc with alpha = occ; the extension's exact footprint is unknown.
-No GPU is involved (BASELINE config 0: "CPU/numpy (plumbing, no GPU)").
+No GPU is involved (BASELINE config 0: "CPU/numpy (plumbing, no GPU)") except for `use_knn_scale` without a
+precomputed `knn_dist2`, which calls the HIP distCUDA2.
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 
@@ -105,18 +108,45 @@ def filter_visible(ply_xyz: np.ndarray, ply_rgb: np.ndarray, c2w: np.ndarray, ix
 
 
 # ---- the point render (render_utils.py:83-183 call-site contract) ---------------------------------
+def knn_point_radii(points: np.ndarray, scale: float, knn_scale_down: float = 1.0,
+                    knn_dist2: Optional[np.ndarray] = None) -> np.ndarray:
+    """The `use_knn_scale` branch of render_pointcloud_diff_point_rasterization (render_utils.py:123-127), the
+    LiDAR path's one consumer of simple_knn:  `dist2 = clamp_min(distCUDA2(xyz), 1e-7)`;
+    `radius = minimum(sqrt(dist2) * knn_scale_down, scale)` -- a point's world radius follows the local point
+    density (mean squared distance to its 3 nearest neighbours) and is capped by `scale`.
+    `knn_dist2`: that mean squared distance per point, when the caller already has it; otherwise it is computed
+    by the product's own `simple_knn._C.distCUDA2` (HIP: needs a GPU -- there is no CPU k-NN in the product)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    if knn_dist2 is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("use_knn_scale needs simple_knn._C.distCUDA2 (a HIP device), or pass knn_dist2=")
+        from simple_knn._C import distCUDA2
+        knn_dist2 = distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    d2 = np.maximum(np.asarray(knn_dist2, dtype=np.float32).reshape(-1), np.float32(0.0000001))
+    if d2.shape[0] != pts.shape[0]:
+        raise ValueError(f"knn_dist2 has {d2.shape[0]} entries for {pts.shape[0]} points")
+    return np.minimum(np.sqrt(d2) * np.float32(knn_scale_down), np.float32(scale)).astype(np.float64)
+
+
 def render_points(c2w: np.ndarray, ixt: np.ndarray, points: np.ndarray, features: np.ndarray, H: int, W: int,
                   occ: float = 1.0, scale: float = 0.035, use_ndc_scale: bool = False, max_hit: int = 10,
-                  near: float = 1.0, far: float = 100.0) -> np.ndarray:
+                  near: float = 1.0, far: float = 100.0, use_knn_scale: bool = False,
+                  knn_scale_down: float = 1.0, knn_dist2: Optional[np.ndarray] = None) -> np.ndarray:
     """-> float32 [1, H, W, 4]: rgb composited front to back over a black background, and alpha.
 
     Radius rule: world radius `scale`; with `use_ndc_scale` the world radius is scale * z / fx * 0.5 *
-    min(H, W) (render_utils.py:116-122), i.e. a constant scale * 0.5 * min(H, W) pixels on screen.
+    min(H, W) (render_utils.py:116-122), i.e. a constant scale * 0.5 * min(H, W) pixels on screen; else with
+    `use_knn_scale` it follows the local point density, capped by `scale` (:123-127, see knn_point_radii;
+    `use_ndc_scale` wins when both are set, as in the reference's if / elif).
     Per pixel the `max_hit` nearest covering points are blended with alpha = occ (:160).  Points outside
     [near, far] in depth are dropped (the camera is built with znear = 1, zfar = 100, :133-134)."""
     img = np.zeros((1, H, W, 4), np.float32)
     if points.shape[0] == 0:
         return img
+    knn_r = None
+    if use_knn_scale and not use_ndc_scale:          # over ALL points handed in, before the depth filter (:125)
+        knn_r = knn_point_radii(points, scale, knn_scale_down, knn_dist2)
     w2c = np.linalg.inv(np.asarray(c2w, np.float64))
     cam = points.astype(np.float64) @ w2c[:3, :3].T + w2c[:3, 3]
     z = cam[:, 2]
@@ -124,11 +154,15 @@ def render_points(c2w: np.ndarray, ixt: np.ndarray, points: np.ndarray, features
     cam, z, rgb = cam[keep], z[keep], np.asarray(features, np.float64)[keep, :3]
     if z.size == 0:
         return img
+    if knn_r is not None:
+        knn_r = knn_r[keep]
     fx, fy, cx, cy = ixt[0, 0], ixt[1, 1], ixt[0, 2], ixt[1, 2]
     u = fx * cam[:, 0] / z + cx
     v = fy * cam[:, 1] / z + cy
     if use_ndc_scale:
         world_r = scale * z / fx * (0.5 * H if H <= W else 0.5 * W)
+    elif knn_r is not None:
+        world_r = knn_r
     else:
         world_r = np.full_like(z, scale)
     rad = world_r * fx / z                                    # pixels

@@ -3,6 +3,7 @@ CPU only.  PARITY UNPINNED: the reference keeps no output for this path and its 
 (diff_point_rasterization) is not available; these tests check the frame assembly, the visibility
 filter, the radius rule and the output contract of the call site (see lidar_condition.py)."""
 import numpy as np
+import pytest
 
 from street_crafter_amd import lidar_condition as lc
 
@@ -93,3 +94,41 @@ def test_condition_frame_end_to_end():
     assert red.sum() > 0                                                  # the tracked car is in view
     rgb_s, _ = lc.render_condition_frame(ply, track, ego, ego[2], 2, ext, ixt, 128, 192, delta_frames=2, shift=2.0)
     assert (rgb_s != rgb).any()
+
+
+def test_use_knn_scale_radius_rule():
+    """render_utils.py:123-127: radius = min(sqrt(clamp_min(distCUDA2(xyz), 1e-7)) * knn_scale_down, scale); the
+    k-NN distances come from the oracle here (tests only) -- on a GPU the product calls its own distCUDA2."""
+    from oracle import knn_oracle as KO
+    from street_crafter_amd.lidar_condition import knn_point_radii, render_points
+    rng = np.random.default_rng(4)
+    dense = rng.normal(scale=0.02, size=(400, 3)) + np.array([0.0, 0.0, 10.0])       # tight cluster
+    sparse = rng.uniform(-3, 3, size=(60, 3)) + np.array([0.0, 0.0, 12.0])            # isolated points
+    dup = np.repeat(np.array([[1.0, 1.0, 9.0]]), 5, axis=0)                          # duplicates: distance 0
+    pts = np.concatenate([dense, sparse, dup]).astype(np.float32)
+    d2 = KO.dist_cuda2(pts)
+    r = knn_point_radii(pts, scale=0.05, knn_scale_down=1.0, knn_dist2=d2)
+    ref = np.minimum(np.sqrt(np.maximum(d2, np.float32(1e-7))), np.float32(0.05))
+    np.testing.assert_array_equal(r.astype(np.float32), ref)
+    assert (r[400:460] == np.float32(0.05)).all()                 # sparse points: capped by `scale`
+    assert r[:400].max() < 0.05 and r[:400].mean() < 0.02         # dense cluster: density-sized
+    np.testing.assert_allclose(r[460:], np.sqrt(np.float32(1e-7)), rtol=1e-6)       # clamp_min floor
+    half = knn_point_radii(pts, 0.05, knn_scale_down=0.5, knn_dist2=d2)
+    np.testing.assert_allclose(half[:400], 0.5 * r[:400], rtol=1e-6)
+    # through the renderer: knn-sized discs cover fewer pixels than constant `scale` discs, never more
+    c2w, ixt = np.eye(4), np.array([[300.0, 0, 80.0], [0, 300.0, 60.0], [0, 0, 1.0]])
+    feat = np.ones((pts.shape[0], 5), np.float32)
+    const = render_points(c2w, ixt, pts, feat, 120, 160, scale=0.05)
+    knn = render_points(c2w, ixt, pts, feat, 120, 160, scale=0.05, use_knn_scale=True, knn_dist2=d2)
+    assert knn.shape == (1, 120, 160, 4) and 0 < (knn[..., 3] > 0).sum() < (const[..., 3] > 0).sum()
+    assert ((knn[..., 3] > 0) <= (const[..., 3] > 0)).all()
+    # use_ndc_scale wins when both are set (if / elif at :116-127)
+    both = render_points(c2w, ixt, pts, feat, 120, 160, scale=0.01, use_ndc_scale=True, use_knn_scale=True, knn_dist2=d2)
+    ndc = render_points(c2w, ixt, pts, feat, 120, 160, scale=0.01, use_ndc_scale=True)
+    np.testing.assert_array_equal(both, ndc)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            render_points(c2w, ixt, pts, feat, 120, 160, use_knn_scale=True)          # no CPU k-NN in the product
+    with pytest.raises(ValueError):
+        knn_point_radii(pts, 0.05, knn_dist2=d2[:-1])

@@ -279,3 +279,61 @@ def test_two_pass_composite_and_quantisation_restatement():
     np.testing.assert_array_equal(O.quantise_u8(got, "video"), (ref * 255).astype(np.uint8))
     np.testing.assert_array_equal(O.quantise_u8(got, "save_image"),
                                   t(ref).mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).numpy())
+
+
+# ---- committed backward fixtures: drift guard of the gradient oracle ------------------
+def _make_golden():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(root, "tools", "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gradient_oracle_fixture_drift(golden_dir):
+    """tests/golden/bwd_small.npz holds the float64 autograd gradients of oracle/gsplat_torch.py (rasterize on
+    pipeline_small, SH degrees 0-4, projection one output at a time incl. the clamped-Jacobian case).  Recomputing
+    them must reproduce the committed values: a change of the gradient oracle cannot go unnoticed."""
+    mg = _make_golden()
+    fix = _load(golden_dir, "bwd_small.npz")
+    g = _load(golden_dir, "pipeline_small.npz")
+    close = lambda a, b, what: np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-7 * max(1e-30, float(np.abs(b).max())),
+                                                          err_msg=what)
+    # rasterize
+    w_c, w_a = mg.raster_bwd_weights(g["unstable"], int(fix["raster_seed"]))
+    src = (g["means2d"][None], g["conics"][None], g["colors"][None], g["opacities"][None])
+    ref = [torch.from_numpy(a).double().requires_grad_(True) for a in src]
+    pix = []
+    rc, ra = OT.rasterize_to_pixels(ref[0], ref[1], ref[2], ref[3], 128, 96, 16, torch.from_numpy(g["isect_offsets"]),
+                                    torch.from_numpy(g["flatten_ids"]), pixel_grads=pix)
+    ((rc * torch.from_numpy(w_c).double()).sum() + (ra * torch.from_numpy(w_a).double()).sum()).backward()
+    for r_, name in zip(ref, ("means2d", "conics", "colors", "opacities")):
+        close(r_.grad.numpy(), fix[f"raster_v_{name}"], name)
+    close(OT.absgrad_from_pixel_grads(pix, g["means2d"].shape[0]).numpy(), fix["raster_absgrad"], "absgrad")
+    assert (fix["raster_absgrad"] + 1e-6 * fix["raster_absgrad"].max() >= np.abs(fix["raster_v_means2d"][0])).all()
+    # spherical harmonics
+    for deg in range(5):
+        K = (deg + 1) ** 2
+        d = torch.from_numpy(fix["sh_dirs"]).double().requires_grad_(True)
+        c = torch.from_numpy(fix["sh_coeffs"][:, :K]).double().requires_grad_(True)
+        (OT.spherical_harmonics(deg, d, c) * torch.from_numpy(fix["sh_v_colors"]).double()).sum().backward()
+        close(c.grad.numpy(), fix[f"sh_v_coeffs_deg{deg}"], f"sh coeffs {deg}")
+        if deg:
+            close(d.grad.numpy(), fix[f"sh_v_dirs_deg{deg}"], f"sh dirs {deg}")
+    # projection, one output at a time
+    for which in ("plain", "clamped"):
+        means, quats, scales, cam = mg.projection_bwd_case(which)
+        for gi, name in enumerate(mg.PROJ_GROUPS):
+            ref = [t.clone().double().requires_grad_(True) for t in (means, quats, scales)]
+            radii, m2, dep, con, comp = OT.fully_fused_projection(ref[0], ref[1], ref[2], cam.viewmat.double(),
+                                                                  cam.K.double(), 320, 200, near_plane=0.001,
+                                                                  far_plane=1000.0)
+            (m2[:, 0], m2[:, 1], dep, con[:, 0], con[:, 1], con[:, 2], comp)[gi].sum().backward()
+            got = np.concatenate([r.grad.numpy() if r.grad is not None else np.zeros(tuple(r.shape)) for r in ref], axis=1)
+            close(got, fix[f"proj_{which}_{name}"], f"{which} {name}")
+        np.testing.assert_array_equal(radii.numpy(), fix[f"proj_{which}_radii"])
+    assert (fix["proj_clamped_is_clamped"] & (fix["proj_clamped_radii"] > 0)).sum() > 100
+    # a clamped Jacobian kills d(conic) / d(mean_x) through tx: the fixture must show the clamp branch was taken
+    vis = fix["proj_clamped_radii"] > 0
+    assert float(fix["proj_plain_kappa"].max()) > 1000.0 and vis.sum() > 150

@@ -92,6 +92,104 @@ def oracle_vectors():
                         tiny=pts[:3], out_tiny=KO.dist_cuda2(pts[:3]))
 
 
+PROJ_GROUPS = ("means2d_x", "means2d_y", "depths", "conic_a", "conic_b", "conic_c", "compensation")
+
+
+def projection_bwd_case(which):
+    """Inputs of the per-output projection-backward fixture: 'plain' = an ordinary small scene, 'clamped' =
+    Gaussians far off to the side of the frustum but wide enough to reach the image, so that the EWA Jacobian
+    uses the CLAMPED x/z, y/z (the clamp's derivative is zero there)."""
+    import torch
+    from street_crafter_amd.scenes import make_camera, make_scene
+    cam = make_camera(320, 200, 350.0, 350.0, yaw=0.07, shift=(0.2, -0.1, 0.3))
+    if which == "plain":
+        sc = make_scene(360, seed=13, z_range=(1.0, 40.0), scale_range=(0.002, 0.5))    # needles included
+        return sc.means, sc.quats, sc.scales, cam
+    sc = make_scene(360, seed=14, z_range=(2.0, 20.0), scale_range=(0.3, 1.5))
+    m = sc.means.clone()
+    g = torch.Generator().manual_seed(3)
+    lim = 1.3 * 0.5 * 320 / 350.0                       # tan-space clamp limit in x
+    side = torch.where(torch.rand(360, generator=g) < 0.5, -1.0, 1.0)
+    m[:, 0] = m[:, 2] * side * (lim + 0.02 + 0.25 * torch.rand(360, generator=g))
+    limy = 1.3 * 0.5 * 200 / 350.0
+    m[::3, 1] = m[::3, 2] * (limy + 0.02 + 0.1 * torch.rand(120, generator=g))
+    return m.contiguous(), sc.quats, sc.scales, cam
+
+
+def raster_bwd_weights(unstable, seed, W=128, H=96, D=4):
+    """Upstream gradients of the rasterize-backward fixture; threshold-unstable pixels take no part in the loss."""
+    rng = np.random.default_rng(seed)
+    w_c = rng.normal(size=(1, H, W, D)).astype(np.float32)
+    w_a = rng.normal(size=(1, H, W, 1)).astype(np.float32)
+    w_c[unstable] = 0.0
+    w_a[unstable] = 0.0
+    return w_c, w_a
+
+
+def backward_vectors():
+    """gradients of the float64 autograd oracle (oracle/gsplat_torch.py), committed so that
+    (a) drift of the gradient oracle is caught on the CPU and (b) the GPU tests need not recompute it."""
+    import torch
+    from oracle import gsplat_oracle as O
+    from oracle import gsplat_torch as OT
+    out = {}
+    # ---- rasterize backward on pipeline_small (weights regenerated from the stored seed) ----
+    g = np.load(os.path.join(GOLD, "pipeline_small.npz"))
+    N, W, H, D = g["means2d"].shape[0], 128, 96, 4
+    w_c, w_a = raster_bwd_weights(g["unstable"], 2024)
+    src = (g["means2d"][None], g["conics"][None], g["colors"][None], g["opacities"][None])
+    ref = [torch.from_numpy(a).double().requires_grad_(True) for a in src]
+    pix = []
+    rc, ra = OT.rasterize_to_pixels(ref[0], ref[1], ref[2], ref[3], W, H, 16, torch.from_numpy(g["isect_offsets"]),
+                                    torch.from_numpy(g["flatten_ids"]), pixel_grads=pix)
+    ((rc * torch.from_numpy(w_c).double()).sum() + (ra * torch.from_numpy(w_a).double()).sum()).backward()
+    out.update(raster_seed=2024,          # (the weights are regenerated from the seed: raster_bwd_weights())
+               raster_v_means2d=ref[0].grad.numpy(), raster_v_conics=ref[1].grad.numpy(),
+               raster_v_colors=ref[2].grad.numpy(), raster_v_opacities=ref[3].grad.numpy(),
+               raster_absgrad=OT.absgrad_from_pixel_grads(pix, N).numpy())
+    # ---- spherical harmonics backward, degrees 0..4 ----
+    rng = np.random.default_rng(77)
+    dirs = rng.normal(size=(120, 3))
+    dirs *= rng.uniform(0.2, 30.0, size=(120, 1))        # not normalised, as the caller passes them
+    coeffs = rng.normal(size=(120, 25, 3))
+    v_col = rng.normal(size=(120, 3))
+    out.update(sh_dirs=dirs.astype(np.float32), sh_coeffs=coeffs.astype(np.float32), sh_v_colors=v_col.astype(np.float32))
+    for deg in range(5):
+        K = (deg + 1) ** 2
+        d = torch.from_numpy(out["sh_dirs"]).double().requires_grad_(True)
+        c = torch.from_numpy(out["sh_coeffs"][:, :K]).double().requires_grad_(True)
+        (OT.spherical_harmonics(deg, d, c) * torch.from_numpy(out["sh_v_colors"]).double()).sum().backward()
+        out[f"sh_v_coeffs_deg{deg}"] = c.grad.numpy()
+        out[f"sh_v_dirs_deg{deg}"] = d.grad.numpy() if d.grad is not None else np.zeros((120, 3))   # degree 0: constant
+    # ---- projection backward, ONE output at a time (unit upstream gradient on that output only) ----
+    for which in ("plain", "clamped"):
+        means, quats, scales, cam = projection_bwd_case(which)
+        V, K = cam.viewmat.double(), cam.K.double()
+        for gi, name in enumerate(PROJ_GROUPS):
+            ref = [t.clone().double().requires_grad_(True) for t in (means, quats, scales)]
+            radii, m2, dep, con, comp = OT.fully_fused_projection(ref[0], ref[1], ref[2], V, K, 320, 200,
+                                                                  near_plane=0.001, far_plane=1000.0)
+            outs = (m2[:, 0], m2[:, 1], dep, con[:, 0], con[:, 1], con[:, 2], comp)
+            outs[gi].sum().backward()
+            # [N, 10] = d out / d (means 3, quats 4, scales 3); an input an output does not depend on has no grad
+            out[f"proj_{which}_{name}"] = np.concatenate(
+                [r.grad.numpy() if r.grad is not None else np.zeros(tuple(r.shape)) for r in ref], axis=1)
+        out[f"proj_{which}_radii"] = radii.numpy().astype(np.int32)
+        # conditioning of the blurred 2-D covariance, kappa = (a1 + c1)^2 / det1 (>= 4): the fp32 kernel loses
+        # ~eps * kappa in det1 = a1 c1 - b^2, and every conic / compensation gradient divides by det1
+        con64 = con.detach().numpy()
+        det_inv = con64[:, 0] * con64[:, 2] - con64[:, 1] ** 2          # = 1 / det1
+        with np.errstate(all="ignore"):
+            out[f"proj_{which}_kappa"] = np.where(radii.numpy() > 0, (con64[:, 0] + con64[:, 2]) ** 2 / det_inv, 0.0)
+        # rows whose Jacobian is evaluated at the clamp limit
+        x = (means.double() @ V[:3, :3].T + V[:3, 3])
+        tx, ty = (x[:, 0] / x[:, 2]).abs().numpy(), (x[:, 1] / x[:, 2]).abs().numpy()
+        out[f"proj_{which}_is_clamped"] = (tx > 1.3 * 0.5 * 320 / 350.0) | (ty > 1.3 * 0.5 * 200 / 350.0)
+    # gradients are stored as float32 (the float64 values rounded once): the drift test compares at 1e-6
+    out = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in out.items()}
+    np.savez_compressed(os.path.join(GOLD, "bwd_small.npz"), **out)
+
+
 def full_size_digest():
     """S-100k at the full 1920x1280 resolution, stored as seed + digests (CRC32 of the
     raw bytes of every integer / bit-exact float tensor, a coarse 8x8-block summary of the image), so the
@@ -132,6 +230,7 @@ if __name__ == "__main__":
     else:
         print("reference not present: *_ref.npz left untouched")
     oracle_vectors()
+    backward_vectors()
     full_size_digest()
     for f in sorted(os.listdir(GOLD)):
         print(f, os.path.getsize(os.path.join(GOLD, f)))
