@@ -108,7 +108,7 @@ int sc_radix_sort_pairs_u64_i32(uint64_t* keys, int32_t* vals, uint64_t* tmp_key
  *                        A super-tile bucket of up to 3584 records is sorted by one workgroup in LDS; when
  *                        super_capacity is larger, longer buckets are first cut into depth ranges that fit
  *                        (only they pay for it).
- * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 16384, C*N >= 2^28 or
+ * Both return SC_EUNSUPPORTED when C*tile_width*tile_height > 36864 (a 3840x2160 frame has 32400 tiles), C*N >= 2^28 or
  * super_capacity > 220 000; the caller then takes the count/emit/radix-sort route.
  */
 /* n_records < 0: bytes of the count-phase workspace (shared by both calls; holds the visible Gaussians'

@@ -39,7 +39,7 @@ constexpr int BIN_GPT = 4;                       // gaussians per thread in the 
 constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
 constexpr int CNT_GPT = 8;                       // ... and in the count pass, whose cost is the flush of the
 constexpr int CNT_GPB = BIN_THREADS * CNT_GPT;   // per-workgroup grids (A/B on S-1M: 2 -> 36 us, 4 -> 23, 8 -> 19, 16 -> 25)
-constexpr int BIN_MAX_TILES = 16384;             // C * tile_width * tile_height handled by this path
+constexpr int BIN_MAX_TILES = 36864;             // C * tile_width * tile_height handled by this path (a 3840x2160 frame: 32400)
 constexpr int BIN_BIG = 32;                      // rectangles larger than this are walked by a whole wave
 constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
 constexpr unsigned long long KEY_MASK = 0xffffffff0fffffffull;   // (depth, id) without the tile mask
@@ -80,6 +80,10 @@ __device__ __forceinline__ Rect super_rect(const Rect& r, int ss) {
 // dgrid_t : [C][th+1][tw+1]   2-D difference grid over tiles        (-> per-tile counts)
 // dgrid_s : [C][sth+1][stw+1] 2-D difference grid over super-tiles  (-> records per super-tile)
 // chist   : [C][sth][stw]     visible Gaussians by centre super-tile
+// LOCAL: the three grids are accumulated in LDS per workgroup and flushed once (the normal case).  !LOCAL: the
+// grids do not fit the LDS (more than ~38 k cells in all, e.g. a 4K frame) and every Gaussian adds straight to
+// the global grids (9 global atomics per Gaussian instead of 9 LDS ones + the flush).
+template <bool LOCAL>
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, Geo g,
     float tile_size, int C, int32_t* __restrict__ tiles_per_gauss, int* __restrict__ dgrid_t,
@@ -88,11 +92,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     const int nt = C * (g.tile_height + 1) * (g.tile_width + 1);
     const int ns = g.ss ? C * (g.sth + 1) * (g.stw + 1) : 0;
     const int nc = C * g.ST;
-    int* dt = lds_i;
-    int* ds = lds_i + nt;
-    int* ch = lds_i + nt + ns;
-    for (int i = threadIdx.x; i < nt + ns + nc; i += BIN_THREADS) lds_i[i] = 0;
-    __syncthreads();
+    int* dt = LOCAL ? lds_i : dgrid_t;
+    int* ds = LOCAL ? lds_i + nt : dgrid_s;
+    int* ch = LOCAL ? lds_i + nt + ns : reinterpret_cast<int*>(chist);
+    if (LOCAL) {
+        for (int i = threadIdx.x; i < nt + ns + nc; i += BIN_THREADS) lds_i[i] = 0;
+        __syncthreads();
+    }
     const int64_t base = (int64_t)blockIdx.x * CNT_GPB;
 #pragma unroll
     for (int k = 0; k < CNT_GPT; ++k) {
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
         const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
         atomicAdd(&ch[cam * g.ST + cy * g.stw + cx], 1);
     }
+    if (!LOCAL) return;
     __syncthreads();
     for (int i = threadIdx.x; i < nt; i += BIN_THREADS) { const int v = dt[i]; if (v) atomicAdd(&dgrid_t[i], v); }
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) { const int v = ds[i]; if (v) atomicAdd(&dgrid_s[i], v); }
@@ -1038,7 +1045,8 @@ static hipError_t bin_attrs_once() {
     std::lock_guard<std::mutex> lock(mu);
     if (done[dev]) return hipSuccess;
     const int a = hipFuncAttributeMaxDynamicSharedMemorySize;
-    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
     done[dev] = true;
@@ -1088,7 +1096,9 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     if (!means2d || !radii || !depths || !tiles_per_gauss || !isect_offsets || !count_workspace) return SC_EINVAL;
     const BinLayout L = bin_layout(CN, C, N, tile_width, tile_height);
     if (ws_bytes < L.total) return SC_EWORKSPACE;
-    if (count_lds_bytes(L) > 150 * 1024 || (size_t)L.nt_cells * 4 > 150 * 1024) return SC_EUNSUPPORTED;
+    // the grid-scan job keeps the tile grid in LDS, the centre pass 12 B per super-tile
+    if ((size_t)L.nt_cells * 4 > 150 * 1024 || (size_t)L.nsb * 12 > 150 * 1024) return SC_EUNSUPPORTED;
+    const bool local_grids = count_lds_bytes(L) <= 150 * 1024;
     unsigned char* ws = (unsigned char*)count_workspace;
     int* dgrid_t = (int*)(ws + L.dgrid_t);
     int* dgrid_s = (int*)(ws + L.dgrid_s);
@@ -1100,9 +1110,13 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
     SC_HIP(bin_attrs_once());
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
-                       count_lds_bytes(L), s, means2d, radii, CN,
-                       L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
+    if (local_grids)
+        hipLaunchKernelGGL(bin_count_kernel<true>, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
+                           count_lds_bytes(L), s, means2d, radii, CN,
+                           L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
+    else
+        hipLaunchKernelGGL(bin_count_kernel<false>, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
+                           0, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
     SC_LAUNCH_CHECK();
     // tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3]: two extra
     // blocks of the centre-scatter launch (see the kernel)

@@ -20,9 +20,9 @@ ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
 for it in range(ROUNDS):
     n = int(rng.choice([1, 7, 500, 20_000, 150_000, 600_000]))
-    W = int(rng.integers(17, 2200)); H = int(rng.integers(17, 1400))
+    W = int(rng.integers(17, 4000)); H = int(rng.integers(17, 2300))
     C = int(rng.choice([1, 1, 2, 3]))
-    if C * ((W + 15) // 16) * ((H + 15) // 16) > 16000:
+    if C * ((W + 15) // 16) * ((H + 15) // 16) > 36000:
         C = 1
     smax = float(rng.choice([0.02, 0.15, 0.6, 3.0]))
     zmin = float(rng.choice([0.5, 2.0, 10.0]))
