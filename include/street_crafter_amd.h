@@ -131,6 +131,12 @@ int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* d
                       int64_t capacity, int64_t rec_capacity, int64_t super_capacity,
                       int64_t* isect_ids /* nullable */, int32_t* flatten_ids,
                       void* workspace, size_t ws_bytes, sc_stream_t stream);
+/* isect_ids from the sorted lists: isect_ids[k] = (camera << (32 + tile_bits)) | (tile << 32) | bits(depths[
+ * flatten_ids[k]]) for every k in tile's range of isect_offsets.  Lets a caller skip the 8 B x I key array in
+ * sc_isect_bin_sort (isect_ids = NULL) and produce it only if somebody asks for it. */
+int sc_isect_ids_rebuild(const int32_t* flatten_ids, const int32_t* isect_offsets, const float* depths,
+                         int C, int N, int tile_width, int tile_height, int64_t n_isects,
+                         int64_t* isect_ids, sc_stream_t stream);
 /* Re-zero the sort phase's bucket cursors / fallback flags inside `count_workspace`: call before a
  * SECOND sc_isect_bin_sort of the same count phase (retry after an under-predicted capacity). */
 int sc_isect_bin_reset_cursors(void* count_workspace, int64_t CN, int C, int tile_width, int tile_height,

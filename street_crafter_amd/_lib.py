@@ -46,6 +46,8 @@ SIGNATURES = {
     "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_i32p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i64p,
                                     c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+    "sc_isect_ids_rebuild": (C.c_int, [c_i32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, c_i64p,
+                                       c_stream]),
     "sc_isect_bin_reset_cursors": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, c_stream]),
     "sc_isect_offsets": (C.c_int, [c_i64p, C.c_int64, C.c_int, C.c_int, C.c_int, c_i32p, c_stream]),
     "sc_sh_fwd": (C.c_int, [C.c_int, c_f32p, c_f32p, c_u8p, C.c_int64, C.c_int, c_f32p, c_stream]),

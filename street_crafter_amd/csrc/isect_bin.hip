@@ -796,6 +796,28 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
                  flatten_ids, nullptr, dbg);
 }
 
+// ---- isect_ids on demand ------------------------------------------------------------------------------------
+// isect_ids[k] = (camera << (32 + tile_bits)) | (tile << 32) | depth bits of the Gaussian at position k of the
+// sorted lists: everything needed is in flatten_ids, isect_offsets and depths, so the 8 B x I key array need not
+// be written by the sort at all (nothing on the reference's path reads it: street_crafter_amd/lazy.py).  One
+// workgroup per (camera, tile).
+__global__ __launch_bounds__(256) void isect_ids_rebuild_kernel(
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, const float* __restrict__ depths,
+    int n_tiles_total, int tiles_per_cam, int tile_bits, int64_t CN, int64_t n_isects, int64_t* __restrict__ isect_ids) {
+    const int tflat = blockIdx.x;
+    const int cam = tflat / tiles_per_cam, tile = tflat - cam * tiles_per_cam;
+    int s = offsets[tflat];
+    int e = (tflat + 1 < n_tiles_total) ? offsets[tflat + 1] : (int)n_isects;
+    s = min(max(s, 0), (int)n_isects);
+    e = min(max(e, s), (int)n_isects);
+    const long long hi = ((long long)cam << (32 + tile_bits)) | ((long long)tile << 32);
+    for (int k = s + (int)threadIdx.x; k < e; k += 256) {
+        const int g = flatten_ids[k];
+        const unsigned d = ((unsigned)g < (unsigned)CN) ? __float_as_uint(depths[g]) : 0u;
+        isect_ids[k] = hi | (long long)d;
+    }
+}
+
 // ---- oversized buckets: cut into depth ranges that fit the LDS sort ---------------------------------------
 // One workgroup per oversized super-tile (n > cap records; grid-stride over the super-tiles):
 //   1. min / max of the 60-bit key; histogram of the records over BS_NB bins of a monotone linear map;
@@ -1144,6 +1166,21 @@ extern "C" int sc_isect_bin_reset_cursors(void* count_workspace, int64_t CN, int
     if ((int64_t)C * tile_width * tile_height > BIN_MAX_TILES) return SC_EUNSUPPORTED;
     const BinLayout L = bin_layout(CN, C, 1, tile_width, tile_height);
     SC_HIP(hipMemsetAsync((unsigned char*)count_workspace + L.rcursor, 0, L.scans_done - L.rcursor, sc_s(stream)));   // rcursor + nseg
+    return SC_OK;
+}
+
+extern "C" int sc_isect_ids_rebuild(const int32_t* flatten_ids, const int32_t* isect_offsets, const float* depths,
+                                    int C, int N, int tile_width, int tile_height, int64_t n_isects,
+                                    int64_t* isect_ids, sc_stream_t stream) {
+    if (C < 0 || N < 0 || tile_width <= 0 || tile_height <= 0 || n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
+    if (C == 0 || n_isects == 0) return SC_OK;
+    if (!flatten_ids || !isect_offsets || !depths || !isect_ids) return SC_EINVAL;
+    const int64_t nb = (int64_t)C * tile_width * tile_height;
+    if (nb > 0x7fffffffLL) return SC_EINVAL;
+    hipLaunchKernelGGL(isect_ids_rebuild_kernel, dim3((unsigned)nb), dim3(256), 0, sc_s(stream), flatten_ids, isect_offsets,
+                       depths, (int)nb, tile_width * tile_height, sc_bits_for((int64_t)tile_width * tile_height),
+                       (int64_t)C * N, n_isects, isect_ids);
+    SC_LAUNCH_CHECK();
     return SC_OK;
 }
 

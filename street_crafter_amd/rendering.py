@@ -237,6 +237,16 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_LAZY_ISECT_IDS = {"on": True}
+
+
+def set_lazy_isect_ids(enabled: bool) -> bool:
+    """isect_tiles' `isect_ids` on the tile-bucketed path: True (default) = a LazyTensor filled on first use
+    (street_crafter_amd/lazy.py: the reference's path never reads it), False = written by the sort as before.
+    Returns the previous setting."""
+    prev, _LAZY_ISECT_IDS["on"] = _LAZY_ISECT_IDS["on"], bool(enabled)
+    return prev
+
 _BIN_LAST_META = {}    # same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
 _PINNED_META = {}      # device index -> [pinned int64[8] the device publishes meta into, its numpy view, seq]
 
@@ -289,8 +299,10 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
                     return tuple(int(v) for v in meta_dev.cpu().tolist())
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
+    eager_ids = want_ids and not _LAZY_ISECT_IDS["on"]
+
     def launch(capacity, rec_capacity, super_capacity):
-        ids = torch.empty(capacity, dtype=torch.int64, device=dev) if want_ids else None
+        ids = torch.empty(capacity, dtype=torch.int64, device=dev) if eager_ids else None
         fids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, rec_capacity), dev)
         r = lib.sc_isect_bin_sort(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
@@ -326,7 +338,22 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     flatten_ids = fids[:n_isects]
     isect_ids = None
     if want_ids:
-        isect_ids = ids[:n_isects]
+        if eager_ids:
+            isect_ids = ids[:n_isects]
+        else:
+            # allocated now, written on first use (one kernel, from flatten_ids / offsets / depths)
+            producer = torch.cuda.current_stream(dev)
+
+            def fill(buf, fl=flatten_ids, off=offsets, dep=depths, producer=producer):
+                cur = torch.cuda.current_stream(dev)
+                if cur != producer:
+                    cur.wait_stream(producer)
+                _lib.check(lib.sc_isect_ids_rebuild(fl.data_ptr(), off.data_ptr(), dep.data_ptr(), C, N,
+                                                    int(tile_width), int(tile_height), n_isects, buf.data_ptr(),
+                                                    cur.cuda_stream), "sc_isect_ids_rebuild")
+
+            from .lazy import LazyTensor
+            isect_ids = LazyTensor(torch.empty(n_isects, dtype=torch.int64, device=dev), fill)
         # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
         # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
         isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)

@@ -170,3 +170,34 @@ def test_bench_algorithmic_bytes_are_the_survey_formula():
                     ("projection", "isect_tiles", "isect_offset_encode", "spherical_harmonics", "rasterize_to_pixels"))
         assert total == per_gauss * N + 88 * I + 24 * P + 4 * T
         assert algorithmic_bytes(N, I, W, H, 16, K) == total
+
+
+def test_lazy_tensor_fills_on_first_read_only():
+    """street_crafter_amd/lazy.py: metadata never triggers the fill, any read does, exactly once."""
+    import numpy as np
+    import torch
+    from street_crafter_amd.lazy import LazyTensor
+    calls = []
+
+    def fill(t):
+        calls.append(t.numel())
+        t.copy_(torch.arange(t.numel(), dtype=t.dtype) * 3)
+
+    z = LazyTensor(torch.empty(7, dtype=torch.int64), fill)
+    assert isinstance(z, torch.Tensor) and not z.is_materialized
+    assert (z.shape, z.numel(), z.dtype, z.dim(), z.is_cuda, str(z.device), z.is_contiguous()) == \
+           (torch.Size([7]), 7, torch.int64, 1, False, "cpu", True)
+    z._sc_note = "attributes can be attached"
+    assert calls == [] and z._version == 0
+    assert (z + 1).tolist() == [1, 4, 7, 10, 13, 16, 19] and calls == [7] and z.is_materialized
+    assert type(z + 1) is torch.Tensor and z[2:4].tolist() == [6, 9] and calls == [7]          # filled once
+    for read in (lambda t: t.cpu(), lambda t: t.numpy(), lambda t: np.asarray(t), lambda t: t.tolist(),
+                 lambda t: t.data_ptr(), lambda t: repr(t), lambda t: torch.equal(t, t.clone()),
+                 lambda t: t.view(torch.int32), lambda t: t.contiguous(), lambda t: torch.cat([t, t]),
+                 lambda t: t.sum().item()):
+        n0 = len(calls)
+        t = LazyTensor(torch.empty(4, dtype=torch.int64), fill)
+        read(t)
+        assert len(calls) == n0 + 1, read
+        assert t.tolist() == [0, 3, 6, 9]
+    assert LazyTensor(torch.empty(0, dtype=torch.int64), fill).materialize().numel() == 0

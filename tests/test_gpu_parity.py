@@ -109,6 +109,43 @@ def test_isect_bit_exact_golden(ops, golden_dir, mode):
     np.testing.assert_array_equal(_np(off), g["isect_offsets"])
 
 
+def test_isect_ids_are_lazy_on_the_bucketed_route_and_exact_when_read(ops, golden_dir):
+    """isect_tiles returns isect_ids as gsplat does, but on the reference's path nothing reads them
+    (renderer.py:253 hands them to isect_offset_encode, whose result the bucketed route already has): the 8 B x I
+    array is a LazyTensor, written by one kernel on first use.  Metadata and isect_offset_encode do not trigger
+    the fill; any read does, and gives exactly the keys the sort used to emit (and the oracle's)."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.lazy import LazyTensor
+    g = _load(golden_dir, "pipeline_small.npz")
+    a = (_t(g["means2d"])[None], _t(g["radii"], torch.int32)[None], _t(g["depths"])[None], 16, 8, 6)
+    tpg, ids, fids = ops.isect_tiles(*a, packed=False, n_cameras=1)
+    assert isinstance(ids, LazyTensor) and not ids.is_materialized
+    assert ids.shape == (g["isect_ids"].shape[0],) and ids.dtype == torch.int64 and ids.is_cuda and ids.numel() == fids.numel()
+    off = ops.isect_offset_encode(ids, 1, 8, 6)
+    assert not ids.is_materialized                                   # the caller's sequence never pays for the keys
+    np.testing.assert_array_equal(_np(off), g["isect_offsets"])
+    np.testing.assert_array_equal(_np(ids), g["isect_ids"])          # first read: filled
+    assert ids.is_materialized
+    assert int((ids >> 32).max()) == int(g["isect_ids"].max() >> 32) and bool(torch.equal(ids[3:9], _t(g["isect_ids"][3:9], torch.int64)))
+    # a second, independent offsets computation from the (now real) keys gives the same answer
+    ids2 = ids.clone()
+    np.testing.assert_array_equal(_np(ops.isect_offset_encode(ids2, 1, 8, 6)), g["isect_offsets"])
+    # filled from another stream: ordered after the producing stream
+    _, ids3, _ = ops.isect_tiles(*a, packed=False, n_cameras=1)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        host = ids3.cpu()
+    np.testing.assert_array_equal(host.numpy(), g["isect_ids"])
+    # eager mode: the sort writes the keys itself
+    prev = rendering.set_lazy_isect_ids(False)
+    try:
+        _, ids4, _ = ops.isect_tiles(*a, packed=False, n_cameras=1)
+        assert not isinstance(ids4, LazyTensor)
+        np.testing.assert_array_equal(_np(ids4), g["isect_ids"])
+    finally:
+        rendering.set_lazy_isect_ids(prev)
+
+
 def test_isect_unsorted_and_empty(ops, golden_dir):
     g = _load(golden_dir, "pipeline_small.npz")
     m2, r, d = _t(g["means2d"])[None], _t(g["radii"], torch.int32)[None], _t(g["depths"])[None]
@@ -179,15 +216,18 @@ def test_isect_depth_ties_keep_index_order(ops, mode, n_depths):
 
 
 def _isect_both_routes(ops, m2, r, d, tw, th, C=1):
+    """-> {"radix": ..., "bin": ... (isect_ids lazy, the default), "bin_eager": ... (keys written by the sort)}"""
     from street_crafter_amd import rendering
     out = {}
-    for mode in ("radix", "bin"):
-        prev = rendering.set_isect_mode(mode)
+    for mode in ("radix", "bin", "bin_eager"):
+        prev = rendering.set_isect_mode(mode.split("_")[0])
+        prev_lazy = rendering.set_lazy_isect_ids(mode != "bin_eager")
         try:
             tpg, ids, fids = ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=C)
             out[mode] = (tpg, ids, fids, ops.isect_offset_encode(ids, C, tw, th))
         finally:
             rendering.set_isect_mode(prev)
+            rendering.set_lazy_isect_ids(prev_lazy)
     return out
 
 
@@ -245,8 +285,8 @@ def test_isect_bin_street_scene_matches_the_radix_route(ops):
         key = (torch.cuda.current_device(), 1, scene.n, 16, 120, 80)
         rendering._BIN_LAST_META.pop(key, None)
         out = _isect_both_routes(ops, m2, r, d, 120, 80)
-        for a, b in zip(out["bin"], out["radix"]):
-            assert torch.equal(a, b)
+        for a, b, c in zip(out["bin"], out["radix"], out["bin_eager"]):
+            assert torch.equal(a, b) and torch.equal(c, b)
         assert key in rendering._BIN_LAST_META                 # the bucketed route took it
     assert rendering._BIN_LAST_META[(torch.cuda.current_device(), 1, 400_000, 16, 120, 80)][2] > 3584
 
