@@ -69,6 +69,11 @@ def parse(argv=None):
                                                "two_pass,street,train")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="debug: every rank uses GPU 0 (exercises the RCCL gather path on a 1-GPU box if RCCL accepts "
+                         "two ranks on one device; numbers are meaningless)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the frame gather (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="launcher / sharding / gather / JSON plumbing on CPU tensors over gloo with a stand-in "
                          "frame source (no renderer, no GPU): what tests/test_dist_cpu.py drives")
@@ -167,7 +172,7 @@ def launch_self(args) -> int:
     GPU (device_count() does not create a context on this image) and never exec()s: children are fresh
     interpreters; rank 0's JSON line goes straight to the inherited stdout."""
     from street_crafter_amd.dist import launch_ranks, visible_gpus
-    if not args.selftest_cpu:
+    if not args.selftest_cpu and not args.oversubscribe:
         have = visible_gpus()
         if have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} requested but this machine exposes {have} GPU(s); "
@@ -210,6 +215,8 @@ def run_rank(args):
         if not torch.cuda.is_available():
             print("bench.py needs a GPU (HIP); there is no CPU path", file=sys.stderr)
             sys.exit(2)
+        if args.oversubscribe:
+            local_rank = 0
         if local_rank >= torch.cuda.device_count():
             print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, "
                   f"{torch.cuda.device_count()} visible)", file=sys.stderr)
@@ -217,7 +224,10 @@ def run_rank(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         if world > 1:
-            dist.init_process_group("nccl", device_id=dev)
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from street_crafter_amd.dist import FrameGatherer, to_uint8_frame
     W, H = args.width, args.height
@@ -326,7 +336,7 @@ def run_rank(args):
     elapsed = elapsed_local
     per_rank_fps = [args.steps / elapsed_local]
     if world > 1:
-        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank_fps = [args.steps / float(x.item()) for x in allt]
@@ -339,6 +349,15 @@ def run_rank(args):
                 expect = (7 * (w_ + (r_ + args.warmup) * world)) % 251
                 assert int(f[0, 0, 0]) == expect and int(f.min()) == int(f.max()), (k, int(f[0, 0, 0]), expect)
 
+    gathered_ok = None
+    if rank == 0 and world > 1 and not selftest:
+        # every rank's first timed frame, as it arrived through the gather, against a local re-render of that frame
+        gathered_ok = True
+        with torch.no_grad():
+            for k in range(world):
+                cam_k = frame_camera(k + args.warmup * world, W, H).to(dev)
+                local = to_uint8_frame(render_gaussians(scene, cam_k)["rgb"])
+                gathered_ok = gathered_ok and bool(torch.equal(local, frames[k]))
     line = None
     if rank == 0:
         fps = args.steps * world / elapsed
@@ -346,7 +365,7 @@ def run_rank(args):
             "metric": METRIC, "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "per_rank_frames_per_s": per_rank_fps,
+            "per_rank_frames_per_s": per_rank_fps, "gathered_frames_match_local_render": gathered_ok,
             "gather": {"frames_per_collective": gatherer.batch, "collectives": gatherer.stats["gathers"],
                        "bytes_into_root_per_collective": gatherer.stats["bytes_per_gather"],
                        "host_ms_issuing_per_collective": (gatherer.stats["host_s_in_gather_calls"] * 1e3 /
