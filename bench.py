@@ -9,13 +9,14 @@ A "step" = every rank renders ONE frame of the synthetic S-1M scene (1 000 000 G
 1920x1280, SURVEY.md 8d / BASELINE.md 2) through the drop-in gsplat operators (the caller's
 sequence of street_gaussian_renderer.py:186-302, forward only) with a per-frame camera and turns it
 into the uint8 frame the novel-view loop keeps; finished frames are gathered to rank 0 (RCCL), K
-frames per collective.  Scene tensors are resident in HBM before the timed region.  Every 8th timed frame is a PROBE frame
-with HIP events around every operator, which is where `roofline` and `stage_ms` come from.  At
---gpus 1 one frame is in flight at a time (a probed kernel runs alone: its HIP-event time is the
-kernel's duration, as rocprofv3 reports it for the same command); at --gpus N > 1 every rank keeps
-`--frames-in-flight` (default 2) independent frames in flight on as many HIP streams (the
-`two_frames_in_flight` line of the N = 1 run is the per-GPU figure to compare with).
-Rank 0 prints ONE JSON line.
+frames per collective.  Scene tensors are resident in HBM before the timed region.  Every rank keeps `--frames-in-flight`
+(default 2) independent frames in flight, frame f on HIP stream f % 2: the latency-bound
+intersection kernels of one frame run under the VALU-bound rasterizer of the other.  Every 8th timed
+frame is a PROBE frame with HIP events around every operator, which is where `roofline` and
+`stage_ms` come from; with two frames in flight a probed kernel shares the GPU with the other
+stream's frame and its time says so (rocprofv3 of the same command sees the same).  The N = 1 run
+therefore also carries `single_stream`: the same K frames one at a time, with the per-kernel times
+and the roofline of kernels running ALONE.  Rank 0 prints ONE JSON line.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the
 GPU) starts the N ranks itself and forwards rank 0's line.
@@ -55,9 +56,9 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=1280)
     ap.add_argument("--sh-degree", type=int, default=1)
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="independent frames each rank keeps in flight, one HIP stream each (default: 1 at "
-                         "--gpus 1, so that per-kernel HIP-event times describe a kernel running alone and agree "
-                         "with rocprofv3 of the same command; 2 at --gpus N > 1)")
+                    help="independent frames each rank keeps in flight, one HIP stream each (default 2 at every "
+                         "--gpus N; 1 = one frame at a time: per-kernel HIP-event times then describe a kernel "
+                         "running alone)")
     ap.add_argument("--gather-batch", type=int, default=8, help="frames per gather collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
@@ -65,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary measurement (keeps rocprof profiles of the headline clean)")
-    ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: two_in_flight,fused,"
+    ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: single_stream,two_in_flight,fused,"
                                                "two_pass,street,train")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
@@ -233,11 +234,11 @@ def run_rank(args):
     W, H = args.width, args.height
     total_steps = args.warmup + args.steps
     if args.frames_in_flight is None:
-        args.frames_in_flight = 1 if world == 1 else 2
+        args.frames_in_flight = 2
     n_streams = 1 if selftest else max(1, args.frames_in_flight)
     skip = set(x for x in args.skip.split(",") if x)
     if args.headline_only:
-        skip |= {"two_in_flight", "fused", "two_pass", "street", "train"}
+        skip |= {"single_stream", "two_in_flight", "fused", "two_pass", "street", "train"}
 
     if selftest:
         W, H = 64, 48
@@ -278,34 +279,37 @@ def run_rank(args):
 
     gatherer = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if (not selftest and n_streams > 1) else None
-    events, n_isects, frame_ev, probe_ev = {}, [], [], []
+    def recorder():
+        return {"events": {}, "n_isects": [], "frame_ev": [], "probe_ev": []}
+
+    main_rec = recorder()
 
     def sync_streams():
         if not selftest:
             torch.cuda.synchronize(dev)
 
-    def run_steps(first, last, timed, g, step_fn, n_str=n_streams, probes=True):
-        """steps [first, last): frame s on stream s % n_str; every 8th timed step is a probe frame with
-        per-operator HIP events (no draining: with n_str > 1 a probed kernel shares the GPU with the other
-        stream's frame and its time says so)."""
+    def run_steps(first, last, timed, g, step_fn, n_str=n_streams, rec=None):
+        """steps [first, last): frame s on stream s % n_str; with a recorder, every 8th timed step is a probe frame
+        with per-operator HIP events (no draining: with n_str > 1 a probed kernel shares the GPU with the other
+        stream's frame and its time says so) and every timed frame gets an event pair."""
         strs = streams[:n_str] if (streams is not None and n_str > 1) else None
         for s in range(first, last):
             r = s - first          # round number of this run (the gatherer is reset between runs)
-            probe = probes and timed and ((s - first) % 8 == 0) and not selftest
+            probe = rec is not None and timed and ((s - first) % 8 == 0) and not selftest
             ctx = torch.cuda.stream(strs[s % n_str]) if strs is not None else None
             if ctx is not None:
                 ctx.__enter__()
             try:
                 ev = None
-                if timed and not selftest:
+                if rec is not None and timed and not selftest:
                     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                     ev[0].record()
-                o = step_fn(s, g.slot(r), events if probe else None, probe)
+                o = step_fn(s, g.slot(r), rec["events"] if probe else None, probe)
                 if ev is not None:
                     ev[1].record()
-                    (probe_ev if probe else frame_ev).append(ev)
+                    rec["probe_ev" if probe else "frame_ev"].append(ev)
                 if probe and o is not None:
-                    n_isects.append(int(o["_isect_ids"].numel()))
+                    rec["n_isects"].append(int(o["_isect_ids"].numel()))
                 g.submit(r)
             finally:
                 if ctx is not None:
@@ -315,14 +319,14 @@ def run_rank(args):
         if world > 1:
             dist.barrier()
 
-    def timed_run(step_fn, g, n_str=n_streams, probes=True):
-        run_steps(0, args.warmup, False, g, step_fn, n_str, probes)
+    def timed_run(step_fn, g, n_str=n_streams, rec=None):
+        run_steps(0, args.warmup, False, g, step_fn, n_str, rec)
         g.drain()
         g.reset()
         barrier()
         sync_streams()
         t0 = time.perf_counter()
-        run_steps(args.warmup, total_steps, True, g, step_fn, n_str, probes)
+        run_steps(args.warmup, total_steps, True, g, step_fn, n_str, rec)
         t_submitted = time.perf_counter()
         frames = g.drain()
         sync_streams()
@@ -331,8 +335,7 @@ def run_rank(args):
         t1 = time.perf_counter()
         return t1 - t0, t1 - t_submitted, frames
 
-    elapsed_local, drain_s, frames = timed_run(render_into, gatherer)
-    headline_frame_ev, headline_probe_ev = list(frame_ev), list(probe_ev)     # (the secondary runs append too)
+    elapsed_local, drain_s, frames = timed_run(render_into, gatherer, rec=main_rec)
     elapsed = elapsed_local
     per_rank_fps = [args.steps / elapsed_local]
     if world > 1:
@@ -403,22 +406,26 @@ def run_rank(args):
                                          rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
                 to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1), out=out)
 
-        def measure(step_fn, n_str, what, compare=None):
-            el, _, fr = timed_run(step_fn, fresh(), n_str, probes=False)
+        def measure(step_fn, n_str, what, compare=None, rec=None):
+            el, _, fr = timed_run(step_fn, fresh(), n_str, rec)
             d = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
                  "frames_in_flight": n_str, "what": what}
             if compare is not None:
                 d["frames_identical_to_headline"] = bool(all(torch.equal(a, b) for a, b in zip(compare, fr)))
             return d, fr
 
-        if "two_in_flight" not in skip:
-            if streams is None:
-                streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-            # what every rank of a --gpus N > 1 run does: frame f on HIP stream f % 2 (frames are independent; the
-            # latency-bound intersection kernels of one frame run under the VALU-bound rasterizer of the other)
+        single_rec = None
+        if streams is None and "two_in_flight" not in skip:
+            streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        if "single_stream" not in skip and n_streams > 1:
+            # one frame at a time (round 1's headline configuration): the probed kernels run ALONE
+            single_rec = recorder()
+            secondary["single_stream"], _ = measure(render_into, 1, "reference caller sequence, ONE frame in flight: "
+                                                    "kernels run alone (round 1's headline configuration)", frames,
+                                                    rec=single_rec)
+        elif "two_in_flight" not in skip and n_streams == 1:
             secondary["two_frames_in_flight"], _ = measure(render_into, 2, "reference caller sequence, two frames in "
-                                                           "flight on two HIP streams (the per-rank configuration of a "
-                                                           "--gpus N > 1 run)", frames)
+                                                           "flight on two HIP streams", frames)
         if "fused" not in skip:
             secondary["fused_rasterization"], _ = measure(
                 fused_into, 1, "gsplat.rendering.rasterization(sh_degree, render_mode='RGB+ED', "
@@ -511,32 +518,61 @@ def run_rank(args):
 
     # ---- per-operator device time from the probe frames' HIP events ----------------------------------------
     torch.cuda.synchronize(dev)
-    stage_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items()}
-    I_mean = sum(n_isects) / max(len(n_isects), 1)
     P, T = W * H, math.ceil(W / 16) * math.ceil(H / 16)
+    traffic_json = {}
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj):
+        try:
+            traffic_json = json.load(open(tj))
+        except Exception:
+            traffic_json = {}
+
+    def kernel_report(rec, in_flight):
+        """stage_ms / operators / roofline of one run's probe frames."""
+        ev = rec["events"]
+        stage = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+        I_m = sum(rec["n_isects"]) / max(len(rec["n_isects"]), 1)
+        ops = {}
+        for k, ms in stage.items():
+            by = stage_algorithmic_bytes(k, args.n_gauss, I_m, P, T, K)
+            ops[k] = {"ms": ms, "algorithmic_bytes": by, "gb_per_s": by / (ms * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": by / (ms * 1e-3) / HBM_PEAK, "kernels": OPERATOR_KERNEL.get(k)}
+        # the dominant KERNEL (not operator): the only operators that are one launch each are projection, SH and
+        # rasterize, and the intersection operator's largest kernel is shorter than the rasterizer (profiles/)
+        dom = "rasterize_to_pixels"
+        dom_ms = stage[dom]
+        dom_bytes = stage_algorithmic_bytes(dom, args.n_gauss, I_m, P, T, K)
+        traffic = traffic_json.get(dom, {}).get(f"n{args.n_gauss}")
+        roof = {"bound": "hbm", "kernel": OPERATOR_KERNEL[dom],
+                "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": dom_bytes / (dom_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                ("profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc "
+                 "passes (committed; not re-measured in this run)"),
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
+                "launches_timed": len(ev.get(dom, [])), "frames_in_flight": in_flight,
+                "how": "HIP events around the rasterize_to_pixels operator (= this one kernel launch) on the probe "
+                       "frames of the timed region" + ("; the kernel runs alone" if in_flight == 1 else
+                       f"; {in_flight} frames in flight: the kernel shares the GPU with the other stream's frame while "
+                       "it is timed (rocprofv3 of the same command sees the same)") +
+                       "; algorithmic bytes = 44 B x I (id + xy + opacity + conic + colour gathered per intersection) "
+                       "+ 24 B x P (SURVEY 8d)",
+                "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound.  Tiles terminate after "
+                        "~12 % of their lists, so the bytes it really moves are ~0.12 of the algorithmic figure "
+                        "(`traffic`); its floor is VALU issue: ~60 VALU instructions incl. 4 v_exp_f32 per blended "
+                        "splat per tile, ~100 us at S-1M (DESIGN.md section 4)"}
+        return stage, ops, roof, I_m
+
+    stage_ms, operators, roofline, I_mean = kernel_report(main_rec, n_streams)
     b_alg = algorithmic_bytes(args.n_gauss, int(I_mean), W, H, 16, K)
 
     if rank == 0:
         fps = line["value"]
-        operators = {}
-        for k, ms in stage_ms.items():
-            by = stage_algorithmic_bytes(k, args.n_gauss, I_mean, P, T, K)
-            operators[k] = {"ms": ms, "algorithmic_bytes": by, "gb_per_s": by / (ms * 1e-3) / 1e9,
-                            "frac_of_hbm_peak": by / (ms * 1e-3) / HBM_PEAK, "kernels": OPERATOR_KERNEL.get(k)}
-        # the dominant KERNEL (not operator): the only operators that are one launch each are projection, SH and
-        # rasterize, and the intersection operator's largest kernel is shorter than the rasterizer (profiles/)
-        dom = "rasterize_to_pixels"
-        dom_ms = stage_ms[dom]
-        dom_bytes = stage_algorithmic_bytes(dom, args.n_gauss, I_mean, P, T, K)
-        traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
-            try:
-                traffic = json.load(open(tj)).get(dom, {}).get(f"n{args.n_gauss}")
-                traffic_src = ("profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE of this kernel from separate "
-                               "rocprofv3 --pmc passes of this command (committed; not re-measured in this run)")
-            except Exception:
-                traffic = None
+        if world == 1 and secondary.get("single_stream") is not None and single_rec is not None:
+            st1, ops1, roof1, _ = kernel_report(single_rec, 1)
+            secondary["single_stream"].update({"stage_ms": st1, "operators": ops1, "roofline": roof1,
+                                               "frame_ms_device": percentiles([a.elapsed_time(b) for a, b in
+                                                                               single_rec["frame_ev"]])})
         line.update({
             "config": {"workload": (f"scene file {os.path.basename(args.scene_ply)} ({args.n_gauss} Gaussians)"
                                     if args.scene_ply else f"S-{args.n_gauss // 1000}k") +
@@ -546,33 +582,21 @@ def run_rank(args):
                                    f"uint8 frames gathered to rank 0 {gatherer.batch} per collective",
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
                        "isect_mode": rendering._ISECT_MODE["mode"], "frames_in_flight": n_streams,
+                       "isect_ids": "lazy (written on first read; nothing on this path reads them)"
+                                    if rendering._LAZY_ISECT_IDS["on"] else "written by the sort",
                        "parallelism": f"frames x{world}"},
-            "roofline": {"bound": "hbm", "kernel": OPERATOR_KERNEL[dom],
-                         "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": dom_bytes / (dom_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
-                         "launches_timed": len(events.get(dom, [])),
-                         "how": "HIP events around the rasterize_to_pixels operator (= this one kernel launch) on "
-                                "the probe frames of the timed region" + ("" if n_streams == 1 else
-                                f", {n_streams} frames in flight: the kernel shares the GPU with the other stream's "
-                                "frame while it is timed") + "; "
-                                "algorithmic bytes = 44 B x I (id + xy + opacity + conic + colour gathered per "
-                                "intersection) + 24 B x P (SURVEY 8d)",
-                         "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound. Tiles "
-                                 "terminate after ~12 % of their lists, so the bytes it really moves are ~0.1 of the "
-                                 "algorithmic figure (`traffic`); its floor is VALU issue: ~60 wave-instructions + "
-                                 "4 v_exp_f32 per blended splat per tile (DESIGN.md section 4)"},
+            "roofline": roofline,
             "operators": operators,
             "frame_roofline": {"algorithmic_bytes_per_frame": b_alg,
                                "hbm_bound_fps_per_gpu": HBM_PEAK / b_alg,
                                "frac_of_hbm_roofline_wall": (fps / world) / (HBM_PEAK / b_alg),
                                "valu_pair_bound": 256 * I_mean},
             "stage_ms": stage_ms,
-            "frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in headline_frame_ev]) or {}),
+            "frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in main_rec["frame_ev"]]) or {}),
                                 "what": f"HIP events around every timed frame that is not a probe frame (operators + "
-                                        f"torch glue + uint8 conversion), {n_streams} frame(s) in flight"},
-            "probe_frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in headline_probe_ev]) or {}),
+                                        f"torch glue + uint8 conversion), {n_streams} frame(s) in flight: with more "
+                                        f"than one, the latency of a frame while it shares the GPU"},
+            "probe_frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in main_rec["probe_ev"]]) or {}),
                                       "what": "the probe frames (10 more event pairs and the intermediates kept)"},
         })
         line.update(secondary)
