@@ -20,6 +20,9 @@
 
 // Diagnostic knobs (sc_set_option("debug0".."debug3", v)); 0 in production.  A non-zero value makes
 // a kernel SKIP part of its work so that the part can be priced; outputs are then invalid.
+// RULE (two GPU memory faults were diagnostic knobs): a skip must leave every index
+// that is derived from the skipped producer IN BOUNDS for every consumer -- skip stores, never the
+// computation of counts / offsets other code indexes with, and bound-check at the consumer anyway.
 extern int g_sc_debug[4];
 
 static inline hipStream_t sc_s(sc_stream_t s) { return (hipStream_t)s; }

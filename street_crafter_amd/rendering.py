@@ -10,6 +10,7 @@ There is no CPU path: non-HIP tensors raise.
 from __future__ import annotations
 
 import math
+import threading
 import time
 from typing import Optional, Tuple
 
@@ -237,6 +238,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_BIN_LOCK = threading.Lock()     # the pinned meta slot + sequence number below are per device, not per thread
 _LAZY_ISECT_IDS = {"on": True}
 
 
@@ -259,11 +261,18 @@ def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
     return n_isects <= capacities[0] and n_records <= capacities[1] and max_super <= capacities[2]
 
 
-def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                     tiles_per_gauss, total_dev, st, want_ids=True):
+def _isect_tiles_bin(*args, **kwargs):
     """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
     the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
-    rasterization() forward never reads it: 16 us of stores per S-1M frame)."""
+    rasterization() forward never reads it).  Host threads are serialised: the count phase reports its sizes
+    through ONE pinned slot + sequence number per device (several frames in flight from one thread are fine:
+    the host handles them one after the other)."""
+    with _BIN_LOCK:
+        return _isect_tiles_bin_locked(*args, **kwargs)
+
+
+def _isect_tiles_bin_locked(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
+                            tiles_per_gauss, total_dev, st, want_ids=True):
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
     meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
