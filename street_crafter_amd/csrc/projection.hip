@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void projection_bwd_kernel(
         const float u0 = ja * Sc[0][0] + jb * Sc[2][0], u1 = ja * Sc[0][1] + jb * Sc[2][1], u2 = ja * Sc[0][2] + jb * Sc[2][2];
         const float w0 = jc * Sc[1][0] + jd * Sc[2][0], w1 = jc * Sc[1][1] + jd * Sc[2][1], w2 = jc * Sc[1][2] + jd * Sc[2][2];
         const float a = u0 * ja + u2 * jb, b = u1 * jc + u2 * jd, cc = w1 * jc + w2 * jd;
-        const float det0 = a * cc - b * b;
         const float a1 = a + eps2d, c1 = cc + eps2d;
         const float det1 = a1 * c1 - b * b;
 

@@ -17,7 +17,7 @@ int g_sc_raster_fwd_variant = 3;
 
 namespace {
 
-constexpr int MAXB = 1024;  // max lanes per tile workgroup (tile_size <= 32)
+
 
 // ------------------------------------------------------------------------------------------
 // variant 0: reference-shaped
