@@ -631,8 +631,8 @@ __device__ __forceinline__ void sort_segment(
         frac = (float)(p - (double)c);    // p - c is exact; (float) rounds monotonically
         return c;
     };
-    // (the bucket of a record is recomputed in every pass rather than kept: ~20 VALU ops against 2 registers per
-    //  record, and the kernel needs <= 80 VGPRs for three workgroups per CU)
+    // (the kernel needs <= 80 VGPRs for three workgroups per CU: the coarse bin is recomputed in the second
+    //  counting pass, the fine bucket is kept from there for the scatter)
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {
         if (t + k * SS_THREADS < n) {
@@ -660,9 +660,15 @@ __device__ __forceinline__ void sort_segment(
         f = f < cnt - 1 ? f : cnt - 1;
         return (int)(cs >> 16) + (f > 0 ? f : 0);
     };
+    int fj[SS_RPT];                            // the fine bucket of each of this thread's records (kept for the scatter)
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k)
-        if (t + k * SS_THREADS < n) atomicAdd(&boff[fine_of(rec_key60(rec[k]))], 1u);
+    for (int k = 0; k < SS_RPT; ++k) {
+        fj[k] = 0;
+        if (t + k * SS_THREADS < n) {
+            fj[k] = fine_of(rec_key60(rec[k]));
+            atomicAdd(&boff[fj[k]], 1u);
+        }
+    }
     __syncthreads();
     {   // exclusive scan of the n fine counters: thread t owns `per` consecutive ones (per is ODD: the
         // lanes' strides then hit 32 distinct banks instead of two)
@@ -689,18 +695,33 @@ __device__ __forceinline__ void sort_segment(
     for (int k = 0; k < SS_RPT; ++k) {
         if (t + k * SS_THREADS < n) {
             const uint2 r = rec[k];
-            const unsigned slot = atomicAdd(&boff[fine_of(rec_key60(r))], 1u);
+            const int f = fj[k];
+            const unsigned slot = atomicAdd(&boff[f], 1u);
             B[slot] = ((unsigned long long)r.x << 32) | r.y;
+            order[slot] = (unsigned short)f;          // the bucket of this position, for the ranking pass
         }
     }
     __syncthreads();
     if (dbg & 2) return;
     // rank inside the fine bucket by (depth bits, flat id) -> order[rank] = position in B.  Consecutive
     // threads take consecutive positions, i.e. neighbouring buckets: the LDS reads stay close together.
-    for (int p = t; p < n; p += SS_THREADS) {
-        const unsigned long long key = B[p];
-        const unsigned long long kk = key & KEY_MASK;
-        const int j = fine_of(((key >> 32) << 28) | (key & ID_MASK));
+    // The bucket of position p was left in order[p] by the scatter (2 bytes instead of re-deriving it from the
+    // key: ~40 VALU ops of double-precision mapping per record); all of a thread's bucket ids are read before
+    // any rank is written, because order[] is also the output.  (One thread per BUCKET ranking its keys in
+    // registers was measured too: 35 us instead of 22 for this phase -- divergence.)
+    unsigned short bj[SS_RPT];
+#pragma unroll
+    for (int k = 0; k < SS_RPT; ++k) {
+        const int p = t + k * SS_THREADS;
+        bj[k] = p < n ? order[p] : (unsigned short)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SS_RPT; ++k) {
+        const int p = t + k * SS_THREADS;
+        if (p >= n) break;
+        const unsigned long long kk = B[p] & KEY_MASK;
+        const int j = bj[k];
         const unsigned beg = j > 0 ? boff[j - 1] : 0u, end = boff[j];
         unsigned r = beg;
         for (unsigned q = beg; q < end; ++q) r += ((B[q] & KEY_MASK) < kk) ? 1u : 0u;

@@ -217,7 +217,7 @@ class FrameGatherer:
 
 
 def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,
-                   group=None, frames_in_flight: int = 1, batch: int = 8) -> Optional[List[torch.Tensor]]:
+                   group=None, frames_in_flight: int = 2, batch: int = 8) -> Optional[List[torch.Tensor]]:
     """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
     (None elsewhere).  n_frames must be a multiple of the world size (every round is one frame per
     rank); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device (if it accepts a
