@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python3 bench.py --steps 8 --warmup 2 --headline-only"
+CMD="python3 bench.py --steps 8 --warmup 2 --headline-only --frames-in-flight 1"
 i=0
 for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY" \
          "FETCH_SIZE" "WRITE_SIZE" \
