@@ -336,7 +336,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 // to BIN_BIG).  Rectangles above BIN_BIG are walked by the whole wave, 64 super-tiles per step.
 // Slots: per-workgroup LDS histogram, one global atomic per (workgroup, touched bucket), LDS cursors.
 constexpr int FLAT_THREADS = 512;                // A/B on S-1M: 256 -> 52 us, 512 -> 47, 1024 -> 51
-constexpr int FLAT_WAVES = FLAT_THREADS / 64;
+constexpr int FLAT_THREADS_SMALL = 128;          // <= 262144 Gaussians: 2 waves x 16 Gaussians per workgroup
 struct FlatTab {                 // per wave
     int rx0[64], rx1[64], ry0[64], ry1[64];        // tile rectangle (for the 2x2 tile mask)
     int sx0[64], sy0[64], sw[64], inv[64];         // super-tile rectangle origin, width, 65536 / width + 1
@@ -345,6 +345,9 @@ struct FlatTab {                 // per wave
     unsigned char owner[64 * BIN_BIG];             // pair number -> lane
 };
 
+// GPW = Gaussians per wave (64, or 16 for small inputs: a wave walks its big rectangles one after the other, and
+// a set of a few ten thousand huge splats -- a sky -- otherwise leaves most SIMDs without a wave)
+template <int FLAT_THREADS, int GPW>
 __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     const uint4* __restrict__ sorted, const int64_t* __restrict__ n_visible, Geo g, int n_sbuckets,
     const int32_t* __restrict__ soffsets, const int64_t* __restrict__ meta, int64_t capacity,
@@ -354,7 +357,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     const int64_t M = n_visible[0];
-    const int64_t base_j = (int64_t)blockIdx.x * FLAT_THREADS;
+    constexpr int GPB = FLAT_THREADS / 64 * GPW;           // Gaussians per workgroup
+    const int64_t base_j = (int64_t)blockIdx.x * GPB;
     if (base_j >= M) return;
     unsigned* hist = lds;                  // [n_sbuckets] counts, then running local cursors
     unsigned* gbase = lds + n_sbuckets;    // [n_sbuckets] global start of this workgroup's slice
@@ -363,11 +367,11 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) hist[b] = 0;
 
     // consecutive lanes take consecutive Gaussians of the spatial order
-    const int64_t j = base_j + threadIdx.x;
+    const int64_t j = base_j + (int64_t)wave * GPW + lane;
     Rect r = {0, 0, 0, 0}, sr = {0, 0, 0, 0};
     int cam_base = 0;
     unsigned depth = 0, id = 0;
-    if (j < M) {
+    if (lane < GPW && j < M) {
         const uint4 pay = sorted[j];
         r.x0 = (int)(pay.x & 0xffffu); r.x1 = (int)(pay.x >> 16);
         r.y0 = (int)(pay.y & 0xffffu); r.y1 = (int)(pay.y >> 16);
@@ -412,8 +416,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
             const int bbase = __builtin_amdgcn_readlane(cam_base, src);
             const unsigned bd = (unsigned)__builtin_amdgcn_readlane((int)depth, src);
             const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)id, src);
+            // q / bw by multiplication: exact for q < 2^32 / bw (an integer division costs ~40 instructions, and a
+            // set of big splats -- a sky -- is walked entirely through this loop)
+            const unsigned binv = 0xffffffffu / (unsigned)bw + 1u;
             for (int q = lane; q < bcnt; q += 64) {
-                const int sy = by0 + q / bw, sx = bx0 + q % bw;
+                const int row = (int)__umulhi((unsigned)q, binv);
+                const int sy = by0 + row, sx = bx0 + (q - row * bw);
                 f(bbase + sy * g.stw + sx, br, sx, sy, bd, bi);
             }
         }
@@ -1089,7 +1097,8 @@ static hipError_t bin_attrs_once() {
     if (done[dev]) return hipSuccess;
     const int a = hipFuncAttributeMaxDynamicSharedMemorySize;
     if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS, 64>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
     done[dev] = true;
@@ -1243,9 +1252,18 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     uint2* temp = (uint2*)((unsigned char*)workspace + rec_bytes);
     Segment* segs = (Segment*)((unsigned char*)workspace + 2 * rec_bytes);
     const int seg_bound = big ? (int)seg_bound_for(rec_capacity, L.nsb) : 0;
-    hipLaunchKernelGGL(bin_scatter_flat_kernel, dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
-                       dim3(FLAT_THREADS), (size_t)L.nsb * 8 + FLAT_WAVES * sizeof(FlatTab), s, sorted, cmeta, L.g, L.nsb,
-                       soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records, g_sc_debug[0]);
+    if (CN > 262144)
+        hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS, 64>), dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
+                           dim3(FLAT_THREADS), (size_t)L.nsb * 8 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
+                           L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records,
+                           g_sc_debug[0]);
+    else {
+        constexpr int gpb = FLAT_THREADS_SMALL / 64 * 16;
+        hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>), dim3((unsigned)((CN + gpb - 1) / gpb)),
+                           dim3(FLAT_THREADS_SMALL), (size_t)L.nsb * 8 + (FLAT_THREADS_SMALL / 64) * sizeof(FlatTab), s,
+                           sorted, cmeta, L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor,
+                           records, g_sc_debug[0]);
+    }
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
     SC_HIP(bin_attrs_once());
