@@ -122,7 +122,10 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* 
                        int tile_size, int tile_width, int tile_height,
                        int32_t* tiles_per_gauss, int32_t* isect_offsets, int64_t* meta_dev /* [4] */,
                        int64_t* meta_mirror /* [5], nullable */, int64_t seq,
-                       void* workspace, size_t ws_bytes, sc_stream_t stream);
+                       void* workspace, size_t ws_bytes,
+                       const int32_t* tile_work /* nullable: [C*tile_width*tile_height], see sc_rasterize_fwd */,
+                       int32_t* tile_order /* nullable: out, the rasterizer's dispatch order built from tile_work */,
+                       sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
                       const int32_t* isect_offsets, const int64_t* meta_dev,
@@ -166,6 +169,12 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                      float* render_colors, float* render_alphas,
                      int32_t* last_ids /* nullable: only the backward pass reads it */,
+                     const int32_t* tile_order /* nullable: a PERMUTATION of the C*tile_width*tile_height flat tile
+                         indices = the order in which the tiles are dispatched (longest-running first: the launch's
+                         makespan is one tile's serial walk plus the throughput part); sc_isect_bin_count builds it */,
+                     int32_t* tile_work /* nullable: [C*tile_width*tile_height], receives the list entries every tile
+                         walked: the scheduling hint the NEXT frame's tile_order is built from (persistent, caller-owned,
+                         zero-initialised; stale or half-updated values are fine) */,
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
@@ -181,7 +190,8 @@ int sc_rasterize_bwd(const float* means2d, const float* conics, const float* col
                      const float* render_alphas, const int32_t* last_ids,
                      const float* v_render_colors, const float* v_render_alphas,
                      float* v_means2d_abs, float* v_means2d, float* v_conics, float* v_colors,
-                     float* v_opacities, sc_stream_t stream);
+                     float* v_opacities, const int32_t* tile_order /* nullable, as sc_rasterize_fwd */,
+                     sc_stream_t stream);
 
 /* ---- a14: simple_knn.distCUDA2 --------------------------------------------------------- */
 size_t sc_knn_workspace_bytes(int64_t n);
@@ -212,7 +222,8 @@ int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* 
                         const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
                         int C, int N, int D, int width, int height, int tile_size, int tile_width,
                         int tile_height, const int32_t* isect_offsets, const int32_t* flatten_ids,
-                        int64_t n_isects, float* render_colors, float* render_alphas, void* workspace,
+                        int64_t n_isects, float* render_colors, float* render_alphas,
+                        const int32_t* tile_order, int32_t* tile_work, void* workspace,
                         size_t ws_bytes, sc_stream_t stream);
 
 /* ---- frame export for the multi-GPU gather: the tail of render_novel_view

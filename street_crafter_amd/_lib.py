@@ -42,7 +42,8 @@ SIGNATURES = {
                                               C.c_void_p, C.c_size_t, c_stream]),
     "sc_isect_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "sc_isect_bin_count": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
-                                     c_i32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, C.c_size_t, c_stream]),
+                                     c_i32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, C.c_size_t, c_i32p, c_i32p,
+                                     c_stream]),
     "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_i32p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i64p,
                                     c_i32p, C.c_void_p, C.c_size_t, c_stream]),
@@ -55,10 +56,10 @@ SIGNATURES = {
                             c_stream]),
     "sc_rasterize_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
-                                   c_f32p, c_f32p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+                                   c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
     "sc_rasterize_fwd_ed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
-                                      c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+                                      c_f32p, c_f32p, c_i32p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
     "sc_camera_centers": (C.c_int, [c_f32p, C.c_int, c_f32p, c_stream]),
     "sc_projection_sh_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -68,7 +69,7 @@ SIGNATURES = {
     "sc_rasterize_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
                                    c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                   c_stream]),
+                                   c_i32p, c_stream]),
     "sc_knn_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "sc_knn3_mean_dist2": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "sc_frame_composite_u8": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int64, C.c_int, c_u8p,

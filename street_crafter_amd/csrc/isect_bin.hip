@@ -248,6 +248,10 @@ __device__ __forceinline__ void publish_meta(const int64_t* __restrict__ meta_de
     mirror[0] = meta_dev[0]; mirror[1] = meta_dev[1]; mirror[2] = meta_dev[2]; mirror[3] = meta_dev[3];
     __hip_atomic_store(&mirror[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void iota_kernel(int32_t* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = i;
+}
 __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_t* mirror, int64_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
 }
@@ -261,7 +265,8 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
     const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
     uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
-    unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq) {
+    unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq,
+    const int32_t* __restrict__ tile_work, int32_t* __restrict__ tile_order, int n_tiles_total, int smooth) {
     extern __shared__ unsigned lds[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
@@ -278,7 +283,56 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         }
         return;
     }
-    const int cblock = (int)blockIdx.x - 2;
+    if (blockIdx.x == 2) {
+        // Dispatch order of the rasterizer's tiles: longest-running first.  tile_work[t] = the work (blend iterations + 8 per staged batch) tile t
+        // walked the LAST time any frame of this shape was rasterized (a scheduling hint: the values may be a
+        // frame or two old or half updated; any values give a valid permutation).  The rasterizer's makespan is
+        // one tile's serial walk (~85 us alone on S-1M) plus the throughput part; starting the long walks first
+        // took 165 -> 137 us on S-1M and 303 -> 222 us on the street scene with exact lengths
+        // (tools/exp_raster_order.py).  Counting sort over 1024 classes of 4 entries, heaviest class first;
+        // the order inside a class is whatever the atomics give (tile order and random order time the same).
+        if (!tile_order) return;
+        unsigned* cls = lds;                 // [1024]
+        unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles]: class of every tile
+        int* wk = reinterpret_cast<int*>(lds + 1024) + (n_tiles_total + 1) / 2;    // [tiles] snapshot of tile_work (smooth only)
+        cls[threadIdx.x] = 0;
+        // tile_work may be written by another stream's rasterizer right now: every value is read ONCE (the two
+        // passes below must agree, or the result would not be a permutation and a tile would go unrendered)
+        if (smooth)
+            for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) wk[i] = tile_work ? tile_work[i] : 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
+            int w = 0;
+            if (smooth) {
+                // the hint is one or two frames old and the camera has moved: a tile inherits the largest work
+                // within 2 tiles of it (a per-frame jitter of 40 px made the plain per-tile hint useless on S-1M)
+                const int cam = i / g.T, rem = i - cam * g.T;
+                const int ty = rem / g.tile_width, tx = rem - ty * g.tile_width;
+                for (int yy = max(ty - 2, 0); yy <= min(ty + 2, g.tile_height - 1); ++yy)
+                    for (int xx = max(tx - 2, 0); xx <= min(tx + 2, g.tile_width - 1); ++xx)
+                        w = max(w, wk[cam * g.T + yy * g.tile_width + xx]);
+            } else if (tile_work) {
+                w = tile_work[i];
+            }
+            const int c = 1023 - min(1023, max(w, 0) >> 2);
+            snap[i] = (unsigned short)c;
+            atomicAdd(&cls[c], 1u);
+        }
+        __syncthreads();
+        long long tot;
+        unsigned mx;
+        const unsigned c = cls[threadIdx.x];
+        const long long run = block_scan_1024((long long)c, 0u, &tot, &mx, wave_tot, wave_max);
+        __syncthreads();
+        cls[threadIdx.x] = (unsigned)run;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
+            const unsigned slot = atomicAdd(&cls[snap[i]], 1u);
+            if (slot < (unsigned)n_tiles_total) tile_order[slot] = i;
+        }
+        return;
+    }
+    const int cblock = (int)blockIdx.x - 3;
     unsigned* hist = lds;                    // [n_sbuckets]
     unsigned* gbase = lds + n_sbuckets;      // [n_sbuckets]
     unsigned* cst = lds + 2 * n_sbuckets;    // [n_sbuckets] first slot of each centre bucket in the spatial order
@@ -1129,7 +1183,8 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
                                   int tile_size,
                                   int tile_width, int tile_height, int32_t* tiles_per_gauss,
                                   int32_t* isect_offsets, int64_t* meta_dev, int64_t* meta_mirror,
-                                  int64_t seq, void* count_workspace, size_t ws_bytes, sc_stream_t stream) {
+                                  int64_t seq, void* count_workspace, size_t ws_bytes, const int32_t* tile_work,
+                                  int32_t* tile_order, sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (!meta_dev) return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
@@ -1141,6 +1196,10 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
         SC_HIP(hipMemsetAsync(meta_dev, 0, 4 * sizeof(int64_t), s));
         if (meta_mirror) {
             hipLaunchKernelGGL(publish_meta_kernel, dim3(1), dim3(64), 0, s, (const int64_t*)meta_dev, meta_mirror, seq);
+            SC_LAUNCH_CHECK();
+        }
+        if (tile_order && nb64 > 0) {         // nothing to rasterize, but the order must still be a permutation
+            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((nb64 + 255) / 256)), dim3(256), 0, s, tile_order, (int)nb64);
             SC_LAUNCH_CHECK();
         }
         return SC_OK;
@@ -1177,11 +1236,15 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     jobs.j[1] = ScanJob{(const int*)dgrid_s, C, L.g.stw, L.g.sth, soffsets, meta_dev + 2, 1};
     jobs.j[2] = jobs.j[1];
     unsigned* scans_done = (unsigned*)(ws + L.scans_done);
-    const size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
-    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 2), dim3(BIN_THREADS), center_lds, s,
+    size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
+    // the order job: 1024 class counters + a class per tile (+ a snapshot of tile_work for the smoothed hint)
+    const int smooth = tile_order && tile_work && 4096 + (size_t)L.ntb * 6 + 8 <= 150 * 1024;
+    const size_t order_lds = 4096 + (size_t)L.ntb * (smooth ? 6 : 2) + 8;
+    if (tile_order && center_lds < order_lds) center_lds = order_lds;
+    hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 3), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
                        depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
-                       meta_mirror, seq);
+                       meta_mirror, seq, tile_work, tile_order, L.ntb, smooth);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -230,15 +230,19 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode,
+    const int32_t* __restrict__ order) {
     constexpr int SB = 2;
     constexpr int B = 64 * SB;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, log2(op), A2
     __shared__ float4 bck_s[B + 1];       // B2, C2, sorted index (int bits), flat id (int bits)
     __shared__ float4 col_s[B + 1];
 
-    int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map")
-    if (map_mode == 0) {
+    int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map", order)
+    if (order) {
+        tflat = order[blockIdx.x];
+        if ((unsigned)tflat >= (unsigned)total_tiles) return;
+    } else if (map_mode == 0) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
         tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -450,7 +454,7 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
                                 int64_t n_isects, const float* render_alphas, const int32_t* last_ids,
                                 const float* v_render_colors, const float* v_render_alphas,
                                 float* v_means2d_abs, float* v_means2d, float* v_conics,
-                                float* v_colors, float* v_opacities, sc_stream_t stream) {
+                                float* v_colors, float* v_opacities, const int32_t* tile_order, sc_stream_t stream) {
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
@@ -469,7 +473,7 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \
                        total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,            \
                        v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities,    \
-                       g_sc_raster_map)
+                       g_sc_raster_map, tile_order)
         if (D == 4) SC_LAUNCH_BWD_WAVE(4);
         else SC_LAUNCH_BWD_WAVE(3);
 #undef SC_LAUNCH_BWD_WAVE

@@ -147,7 +147,7 @@ __device__ __forceinline__ void raster_item(
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
     int32_t* __restrict__ last_ids, int dbg, int tflat, int sub,
-    float4* xyoa_s, float4* bck_s, float4* col_s) {
+    float4* xyoa_s, float4* bck_s, float4* col_s, int32_t* __restrict__ tile_work) {
     constexpr int SB = 2;                 // splats staged per lane per batch
     constexpr int B = 64 * SB;            // batch size
     constexpr int NP = NSUB == 1 ? 2 : 1; // pixel PAIRS per lane
@@ -184,11 +184,14 @@ __device__ __forceinline__ void raster_item(
                 if (last_ids) last_ids[pix0 + k] = 0;
             }
         }
+        if (tile_work && lane == 0 && sub == 0) tile_work[tflat] = 0;
         return;
     }
     int range_start, range_end;
     sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
+    int walked = 0;                       // work done by this wave: blend iterations + 8 per staged batch (the
+                                          // scheduling hint the next frame's dispatch order is built from)
 
     // the rectangle of pixel centres this wave owns (only pixels inside the image count)
     const float rx0 = (float)(txi * 16) + 0.5f;
@@ -258,6 +261,7 @@ __device__ __forceinline__ void raster_item(
     for (int b = 0; b < num_batches; ++b) {
         if (all_done()) break;
         const int batch_start = range_start + B * b;
+        walked += 8;                      // a staged batch (gather + cull) weighs about 8 blend iterations
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
         int bsz = 0;
         __syncthreads();   // single-wave workgroup: orders the previous batch's LDS reads vs these writes
@@ -320,16 +324,17 @@ __device__ __forceinline__ void raster_item(
                         acc[2 * p + h][0] = __fmaf_rn(c.x, vh, acc[2 * p + h][0]);
                         acc[2 * p + h][1] = __fmaf_rn(c.y, vh, acc[2 * p + h][1]);
                         acc[2 * p + h][2] = __fmaf_rn(c.z, vh, acc[2 * p + h][2]);
-                        if (CDIM > 3) acc[2 * p + h][3] = __fmaf_rn(c.w, vh, acc[2 * p + h][3]);
+                        if constexpr (CDIM > 3) acc[2 * p + h][3] = __fmaf_rn(c.w, vh, acc[2 * p + h][3]);
                     }
                     if (TRACK) {
                         cur[2 * p] = b0 ? sidx : cur[2 * p];
                         cur[2 * p + 1] = b1 ? sidx : cur[2 * p + 1];
                     }
                 }
-                if (all_done()) break;
+                if (all_done()) { walked += t + 1 - bsz; break; }
                 a = an; bc = bcn; c = cn;
             }
+            walked += bsz;
         }
     }
 #pragma unroll
@@ -355,6 +360,7 @@ __device__ __forceinline__ void raster_item(
         }
         if (TRACK) last_ids[pix] = cur[k];
     }
+    if (tile_work && lane == 0 && sub == 0) tile_work[tflat] = walked;
 }
 
 template <int CDIM, bool TRACK>
@@ -365,7 +371,8 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg, int map_mode) {
+    int32_t* __restrict__ last_ids, int dbg, int map_mode, const int32_t* __restrict__ order,
+    int32_t* __restrict__ tile_work) {
     constexpr int B = 128;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
     __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
@@ -373,18 +380,24 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     // block -> tile.  Blocks b, b + 8, b + 16, .. share an XCD (and its 4 MiB L2).
     //   map_mode 1 (default): tile = block, i.e. neighbouring tiles go round-robin over the 8 XCDs.  A dense
     //     image region (the horizon band of a street scene) is then spread over all XCDs.
+    //   order (nullable): the dispatch order of the tiles, longest-running first (built by the intersection
+    //     stage from tile_work, the entries every tile walked the last time: center_scatter_kernel, block 2).
+    //     The launch's makespan is one tile's serial walk plus the throughput part, so the long walks start first.
     //   map_mode 0: one contiguous band of tile rows per XCD (more L2 reuse of the gathered parameters; but
     //     the XCD that owns the dense band finishes long after the others: 0.49 vs 0.33 ms on the street scene,
     //     no difference on the uniform S-1M).
     int tflat = blockIdx.x;
-    if (map_mode == 0) {
+    if (order) {
+        tflat = order[blockIdx.x];
+        if ((unsigned)tflat >= (unsigned)total_tiles) return;
+    } else if (map_mode == 0) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
         tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     raster_item<CDIM, TRACK, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                 tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
-                                render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s);
+                                render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s, tile_work);
 }
 
 }  // namespace
@@ -402,8 +415,8 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
                               int tile_size, int tile_width, int tile_height,
                               const int32_t* isect_offsets, const int32_t* flatten_ids,
                               int64_t n_isects, float* render_colors, float* render_alphas,
-                              int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream,
-                              int epilogue) {
+                              int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work, void* workspace,
+                              size_t ws_bytes, sc_stream_t stream, int epilogue) {
     (void)workspace; (void)ws_bytes;
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
@@ -426,7 +439,7 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,        \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
-                       render_alphas, last_ids, kdbg, g_sc_raster_map)
+                       render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work)
         if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
         else { if (last_ids) SC_LAUNCH_WAVE(3, true); else SC_LAUNCH_WAVE(3, false); }
 #undef SC_LAUNCH_WAVE
@@ -460,10 +473,11 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
                                 int tile_size, int tile_width, int tile_height,
                                 const int32_t* isect_offsets, const int32_t* flatten_ids,
                                 int64_t n_isects, float* render_colors, float* render_alphas,
-                                int32_t* last_ids, void* workspace, size_t ws_bytes, sc_stream_t stream) {
+                                int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work, void* workspace,
+                                size_t ws_bytes, sc_stream_t stream) {
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
-                              render_colors, render_alphas, last_ids, workspace, ws_bytes, stream, 0);
+                              render_colors, render_alphas, last_ids, tile_order, tile_work, workspace, ws_bytes, stream, 0);
 }
 
 extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,
@@ -472,8 +486,9 @@ extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, co
                                    int tile_size, int tile_width, int tile_height,
                                    const int32_t* isect_offsets, const int32_t* flatten_ids,
                                    int64_t n_isects, float* render_colors, float* render_alphas,
-                                   void* workspace, size_t ws_bytes, sc_stream_t stream) {
+                                   const int32_t* tile_order, int32_t* tile_work, void* workspace, size_t ws_bytes,
+                                   sc_stream_t stream) {
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
-                              render_colors, render_alphas, nullptr, workspace, ws_bytes, stream, 1);
+                              render_colors, render_alphas, nullptr, tile_order, tile_work, workspace, ws_bytes, stream, 1);
 }

@@ -238,8 +238,26 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_TILE_WORK = {}        # (device index, C, tile_width, tile_height) -> int32 [C * tiles]: the list entries every tile
+                       # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
+_TILE_ORDER = {"on": True}
 _BIN_LOCK = threading.Lock()     # the pinned meta slot + sequence number below are per device, not per thread
 _LAZY_ISECT_IDS = {"on": True}
+
+
+def set_tile_order(enabled: bool) -> bool:
+    """Longest-running-tile-first dispatch of the rasterizer (A/B switch; results are identical either way).
+    Returns the previous setting."""
+    prev, _TILE_ORDER["on"] = _TILE_ORDER["on"], bool(enabled)
+    return prev
+
+
+def _tile_work(dev, C, tile_width, tile_height) -> Tensor:
+    key = (dev.index, int(C), int(tile_width), int(tile_height))
+    t = _TILE_WORK.get(key)
+    if t is None:
+        t = _TILE_WORK[key] = torch.zeros(int(C) * int(tile_width) * int(tile_height), dtype=torch.int32, device=dev)
+    return t
 
 
 def set_lazy_isect_ids(enabled: bool) -> bool:
@@ -286,9 +304,18 @@ def _isect_tiles_bin_locked(lib, means2d, radii, depths, C, N, tile_size, tile_w
     meta_host, meta_np = slot[0], slot[1]
     slot[2] += 1
     seq = slot[2]
+    # the rasterizer's dispatch order (longest-running tiles first) is built here, beside the count kernels, from
+    # what every tile walked the last time (tile_size 16: the wave-per-tile rasterizer)
+    sched = None
+    if _TILE_ORDER["on"] and int(tile_size) == 16:
+        sched = (torch.empty(C * tile_width * tile_height, dtype=torch.int32, device=dev),
+                 _tile_work(dev, C, tile_width, tile_height))
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
-                                meta_host.data_ptr(), seq, _p(ws0), ws0.numel(), st)
+                                meta_host.data_ptr(), seq, _p(ws0), ws0.numel(),
+                                None if sched is None else _p(sched[1]), None if sched is None else _p(sched[0]), st)
+    if sched is not None:
+        offsets._sc_sched = sched          # travels with isect_offsets to rasterize_to_pixels
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
     _lib.check(rc, "sc_isect_bin_count")
@@ -442,6 +469,14 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 # ------------------------------------------------------------------------------------------
 # a9 rasterize_to_pixels  (renderer.py:267-280)
 # ------------------------------------------------------------------------------------------
+def _sched_of(isect_offsets, n_tiles):
+    """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
+    sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
+    if sched is None or sched[0].numel() != n_tiles or sched[0].device != isect_offsets.device:
+        return None, None
+    return sched
+
+
 class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size,
@@ -456,12 +491,12 @@ class _Rasterize(torch.autograd.Function):
         # last_ids only feeds the backward replay: inference (no input requires grad) skips it
         needs_bwd = any(ctx.needs_input_grad[:5])
         last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev) if needs_bwd else None
-        # (the shipped kernels need no scratch: sc_rasterize_workspace_bytes() == 256, nothing is allocated)
+        order, work = _sched_of(isect_offsets, C * tw * th)
         _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
                                         _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
                                         _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-                                        _p(render_colors), _p(render_alphas), _p(last_ids), None, 0,
-                                        _stream(means2d)),
+                                        _p(render_colors), _p(render_alphas), _p(last_ids), _p(order), _p(work),
+                                        None, 0, _stream(means2d)),
                    "sc_rasterize_fwd")
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,
@@ -470,6 +505,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.meta = (int(width), int(height), int(tile_size), bool(absgrad), backgrounds is not None,
                     masks is not None)
         ctx.means2d_obj = means2d_obj
+        ctx.tile_order = order
         return render_colors, render_alphas
 
     @staticmethod
@@ -498,7 +534,8 @@ class _Rasterize(torch.autograd.Function):
                                         C, N, D, width, height, tile_size, tw, th, _p(isect_offsets),
                                         _p(flatten_ids), flatten_ids.numel(), _p(render_alphas), _p(last_ids),
                                         _p(v_render_colors), _p(v_render_alphas), _p(v_abs), _p(v_means2d),
-                                        _p(v_conics), _p(v_colors), _p(v_opacities), _stream(means2d)),
+                                        _p(v_conics), _p(v_colors), _p(v_opacities), _p(ctx.tile_order),
+                                        _stream(means2d)),
                    "sc_rasterize_bwd")
         if absgrad:
             # gsplat contract: the tensor object the CALLER passed gets an `.absgrad` attribute
@@ -656,16 +693,18 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     args = (_p(means2d), _p(conics), _p(cols), _p(opac), _p(backgrounds), None, C, N, 4, int(width), int(height),
             int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
             _p(render_colors), _p(render_alphas))
+    order, work = _sched_of(isect_offsets, C * tile_width * tile_height)
+    sch = (_p(order), _p(work))
     if render_mode == "RGB+ED":
-        rc = lib.sc_rasterize_fwd_ed(*args, None, 0, st)
+        rc = lib.sc_rasterize_fwd_ed(*args, *sch, None, 0, st)
         if rc == -3:          # the reference-shaped raster kernel is selected: plain launch + the torch post-step
-            _lib.check(lib.sc_rasterize_fwd(*args, None, None, 0, st), "sc_rasterize_fwd")
+            _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
             render_colors = torch.cat([render_colors[..., :-1],
                                        render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
         else:
             _lib.check(rc, "sc_rasterize_fwd_ed")
     else:
-        _lib.check(lib.sc_rasterize_fwd(*args, None, None, 0, st), "sc_rasterize_fwd")
+        _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
     meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
                        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
                        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,

@@ -59,9 +59,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_sh_fwd(5, None, None, None, 4, 36, None, None) == -1              # degree > 4
     assert lib.sc_sh_fwd(3, None, None, None, 4, 9, None, None) == -1               # K < 16
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 33, 64, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None, 0, None) == -1        # D > 32
+                                None, None, 0, None, None, None, None, None, None, 0, None) == -1        # D > 32
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 3, 65, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None, 0, None) == -1        # tiles too few
+                                None, None, 0, None, None, None, None, None, None, 0, None) == -1        # tiles too few
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 10, 65, None, 0, None) == -1
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 1, 40, None, 0, None) == 0   # n<=1 no-op
     # fused forward entries
@@ -74,8 +74,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_projection_sh_fwd(None, None, None, None, None, None, None, None, 1, 0, 4, 1, 64, 64, 0.3, 0.01,
                                     1e10, 0.0, 1, None, None, None, None, None, None, None) == 0      # N == 0
     assert lib.sc_rasterize_fwd_ed(None, None, None, None, None, None, 1, 4, 3, 64, 64, 16, 4, 4,
-                                   None, None, 0, None, None, None, 0, None) in (-1, -3)   # needs D == 4
-    assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None) == -1
+                                   None, None, 0, None, None, None, None, None, 0, None) in (-1, -3)   # needs D == 4
+    assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None, None,
+                                  None) == -1
     assert lib.sc_knn3_mean_dist2(None, 0, None, None, 0, None) == 0
     assert lib.sc_knn_workspace_bytes(1000) >= 1000 * 36
     assert lib.sc_isect_workspace_bytes(1_000_000) >= (1_000_000 // 256) * 8
