@@ -474,7 +474,10 @@ def run_rank(args):
                 d, _ = measure(street_into, 1, f"street-shaped scene, {n_st} foreground Gaussians, caller sequence, one frame in flight")
                 torch.cuda.synchronize(dev)
                 d["n_isects"] = street_into.I
-                d["stage_ms"] = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev_st.items()}
+                # median over the probe frames (every 8th, warm-up included: its first frame runs with exact sizes
+                # after a host round trip, which a mean would carry)
+                d["stage_ms"] = {k: sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2] for k, v in ev_st.items()}
+                d["stage_ms_is"] = "median over the probe frames"
                 meta = rendering._BIN_LAST_META.get(key)
                 if meta:
                     d["largest_super_tile_records"] = meta[2]

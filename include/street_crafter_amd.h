@@ -124,7 +124,8 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* 
                        int64_t* meta_mirror /* [5], nullable */, int64_t seq,
                        void* workspace, size_t ws_bytes,
                        const int32_t* tile_work /* nullable: [C*tile_width*tile_height], see sc_rasterize_fwd */,
-                       int32_t* tile_order /* nullable: out, the rasterizer's dispatch order built from tile_work */,
+                       int32_t* tile_order /* nullable: out, the rasterizer's dispatch list built from tile_work:
+                           sc_tile_order_len(C*tile_width*tile_height) items, see sc_rasterize_fwd */,
                        sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
@@ -169,14 +170,20 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                      float* render_colors, float* render_alphas,
                      int32_t* last_ids /* nullable: only the backward pass reads it */,
-                     const int32_t* tile_order /* nullable: a PERMUTATION of the C*tile_width*tile_height flat tile
-                         indices = the order in which the tiles are dispatched (longest-running first: the launch's
-                         makespan is one tile's serial walk plus the throughput part); sc_isect_bin_count builds it */,
+                     const int32_t* tile_order /* nullable: the DISPATCH LIST, sc_tile_order_len(C*tile_width*tile_height)
+                         items, one per workgroup in launch order (longest-running first: the launch's makespan is one
+                         tile's serial walk plus the throughput part).  item = flat tile << 2 | kind: kind 0 = the whole
+                         tile, 1 / 2 = its upper / lower 16 x 8 half (a tile whose walk would be the launch's tail is
+                         shared by two waves); negative = no work.  Every tile must appear exactly once as kind 0 or
+                         once as each of kinds 1 and 2 (a tile that does not appear is not rendered).
+                         sc_isect_bin_count builds it */,
                      int32_t* tile_work /* nullable: [C*tile_width*tile_height], receives the list entries every tile
                          walked: the scheduling hint the NEXT frame's tile_order is built from (persistent, caller-owned,
                          zero-initialised; stale or half-updated values are fine) */,
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
+/* number of int32 items in a dispatch list for `total_tiles` tiles (every tile + room for the split ones) */
+int sc_tile_order_len(int total_tiles);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
  * with scratch needs no ABI change) */
 size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height);
@@ -249,6 +256,8 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
  *                     3 = one wave per tile, 4 pixels per lane, exact tile-level cull (default)
  *   key "raster_map": block -> tile map of the wave rasterizer: 1 = neighbouring tiles round-robin over the
  *                     8 XCDs (default), 0 = one band of tile rows per XCD
+ *   key "raster_split": 0..100: the dispatch list sc_isect_bin_count builds lists a tile as two 16 x 8 halves when
+ *                     its work hint is at least this percentage of the heaviest tile's (default 50; 0 = never)
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)

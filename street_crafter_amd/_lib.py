@@ -66,6 +66,7 @@ SIGNATURES = {
                                        C.c_float, C.c_float, C.c_float, C.c_int, c_i32p, c_f32p, c_f32p,
                                        c_f32p, c_f32p, c_f32p, c_stream]),
     "sc_rasterize_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sc_tile_order_len": (C.c_int, [C.c_int]),
     "sc_rasterize_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
                                    c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

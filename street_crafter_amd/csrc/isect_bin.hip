@@ -266,7 +266,8 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
     uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
     unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq,
-    const int32_t* __restrict__ tile_work, int32_t* __restrict__ tile_order, int n_tiles_total, int smooth) {
+    const int32_t* __restrict__ tile_work, int32_t* __restrict__ tile_order, int n_tiles_total, int smooth,
+    int split_pct) {
     extern __shared__ unsigned lds[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
@@ -284,23 +285,37 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         return;
     }
     if (blockIdx.x == 2) {
-        // Dispatch order of the rasterizer's tiles: longest-running first.  tile_work[t] = the work (blend iterations + 8 per staged batch) tile t
-        // walked the LAST time any frame of this shape was rasterized (a scheduling hint: the values may be a
-        // frame or two old or half updated; any values give a valid permutation).  The rasterizer's makespan is
-        // one tile's serial walk (~85 us alone on S-1M) plus the throughput part; starting the long walks first
-        // took 165 -> 137 us on S-1M and 303 -> 222 us on the street scene with exact lengths
-        // (tools/exp_raster_order.py).  Counting sort over 1024 classes of 4 entries, heaviest class first;
-        // the order inside a class is whatever the atomics give (tile order and random order time the same).
+        // The rasterizer's DISPATCH LIST (include/street_crafter_amd.h, sc_rasterize_fwd): longest-running tiles
+        // first, and the tiles whose walk would be the launch's tail shared by two waves (16 x 8 halves).
+        // tile_work[t] = the work (blend iterations + 8 per staged batch) tile t reported the LAST time a frame of
+        // this shape was rasterized -- a scheduling hint: the values may be a frame or two old or half updated; any
+        // values give a valid list.  The launch's makespan is one tile's serial walk plus the throughput part:
+        // heaviest-first took S-1M 150 -> 140 us and the street scene 292 -> 234 us, halving every tile within a
+        // factor 2 of the heaviest (at most one tile in eight) a further -> 133 / 152 us, with exact hints
+        // (tools/exp_raster_split.py).  Counting sort over 1024 classes of work, heaviest class first; the order
+        // inside a class is whatever the atomics give (tile order and random order time the same).
         if (!tile_order) return;
         unsigned* cls = lds;                 // [1024]
         unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles]: class of every tile
         int* wk = reinterpret_cast<int*>(lds + 1024) + (n_tiles_total + 1) / 2;    // [tiles] snapshot of tile_work (smooth only)
+        __shared__ int s_lim, s_nsplit;
+        const int n_items_max = n_tiles_total + n_tiles_total / 8 + 8;             // == sc_tile_order_len
+        const int cap = n_tiles_total / 8;
         cls[threadIdx.x] = 0;
-        // tile_work may be written by another stream's rasterizer right now: every value is read ONCE (the two
-        // passes below must agree, or the result would not be a permutation and a tile would go unrendered)
-        if (smooth)
-            for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) wk[i] = tile_work ? tile_work[i] : 0;
-        __syncthreads();
+        if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; }
+        // tile_work may be written by another stream's rasterizer right now: every value that decides a tile's
+        // place is read ONCE (the passes below must agree, or a tile would be listed twice or not at all)
+        unsigned lmax = 0;
+        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
+            const int w = tile_work ? max(tile_work[i], 0) : 0;
+            if (smooth) wk[i] = w;
+            lmax = max(lmax, (unsigned)w);
+        }
+        long long tot;
+        unsigned wmax;
+        block_scan_1024(0, lmax, &tot, &wmax, wave_tot, wave_max);     // (syncs: the snapshot is complete)
+        int shift = 0;
+        while ((wmax >> shift) > 1023u) ++shift;
         for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
             int w = 0;
             if (smooth) {
@@ -312,24 +327,36 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
                     for (int xx = max(tx - 2, 0); xx <= min(tx + 2, g.tile_width - 1); ++xx)
                         w = max(w, wk[cam * g.T + yy * g.tile_width + xx]);
             } else if (tile_work) {
-                w = tile_work[i];
+                w = max(tile_work[i], 0);
             }
-            const int c = 1023 - min(1023, max(w, 0) >> 2);
+            const int c = 1023 - min(1023, w >> shift);
             snap[i] = (unsigned short)c;
             atomicAdd(&cls[c], 1u);
         }
         __syncthreads();
-        long long tot;
+        const unsigned cnt = cls[threadIdx.x];
         unsigned mx;
-        const unsigned c = cls[threadIdx.x];
-        const long long run = block_scan_1024((long long)c, 0u, &tot, &mx, wave_tot, wave_max);
+        const long long run = block_scan_1024((long long)cnt, 0u, &tot, &mx, wave_tot, wave_max);
+        // classes [0, lim) are split: those whose work is at least split_pct % of the heaviest tile's, as far as
+        // the list has room (heavier classes first, whole classes only)
+        const int c_split = 1023 - (int)((((unsigned long long)wmax * (unsigned)split_pct) / 100u) >> shift);
+        const bool mine = split_pct > 0 && wmax >= 32u && (int)threadIdx.x <= c_split && run + cnt <= cap;
+        if (mine) { atomicAdd(&s_lim, 1); atomicMax(&s_nsplit, (int)(run + cnt)); }
         __syncthreads();
-        cls[threadIdx.x] = (unsigned)run;
+        const int lim = s_lim, n_split = s_nsplit;       // `mine` holds on a prefix of the classes
+        cls[threadIdx.x] = (int)threadIdx.x < lim ? (unsigned)(2 * run) : (unsigned)(run + n_split);
         __syncthreads();
         for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
-            const unsigned slot = atomicAdd(&cls[snap[i]], 1u);
-            if (slot < (unsigned)n_tiles_total) tile_order[slot] = i;
+            const int c = snap[i];
+            if (c < lim) {
+                const unsigned slot = atomicAdd(&cls[c], 2u);
+                if (slot + 1 < (unsigned)n_items_max) { tile_order[slot] = i << 2 | 1; tile_order[slot + 1] = i << 2 | 2; }
+            } else {
+                const unsigned slot = atomicAdd(&cls[c], 1u);
+                if (slot < (unsigned)n_items_max) tile_order[slot] = i << 2;
+            }
         }
+        for (int i = n_tiles_total + n_split + threadIdx.x; i < n_items_max; i += BIN_THREADS) tile_order[i] = -1;
         return;
     }
     const int cblock = (int)blockIdx.x - 3;
@@ -1244,7 +1271,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 3), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
                        depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
-                       meta_mirror, seq, tile_work, tile_order, L.ntb, smooth);
+                       meta_mirror, seq, tile_work, tile_order, L.ntb, smooth, g_sc_raster_split);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

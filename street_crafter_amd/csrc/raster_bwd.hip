@@ -240,8 +240,12 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
 
     int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map", order)
     if (order) {
-        tflat = order[blockIdx.x];
-        if ((unsigned)tflat >= (unsigned)total_tiles) return;
+        // the forward's dispatch list (sc_tile_order_len items): a tile the forward splits appears as kinds 1 and 2
+        // (halves); the backward takes the whole tile at the first and nothing at the second
+        const int item = order[blockIdx.x];
+        if (item < 0 || (item & 3) >= 2) return;
+        tflat = item >> 2;
+        if (tflat >= total_tiles) return;
     } else if (map_mode == 0) {
         const int nwg = gridDim.x, bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -467,9 +471,11 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     if ((int64_t)C * N > 0x7fffffffLL) return SC_EINVAL;
     if (g_sc_raster_bwd_variant == 1 && tile_size == 16 && (D == 3 || D == 4)) {
+        if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
+        const int n_blocks = tile_order ? sc_tile_order_len(total_tiles) : total_tiles;
 #define SC_LAUNCH_BWD_WAVE(CD)                                                                                  \
-    hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d, conics,   \
+    hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, conics,      \
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \
                        total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,            \
                        v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities,    \

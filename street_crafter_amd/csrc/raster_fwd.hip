@@ -184,7 +184,7 @@ __device__ __forceinline__ void raster_item(
                 if (last_ids) last_ids[pix0 + k] = 0;
             }
         }
-        if (tile_work && lane == 0 && sub == 0) tile_work[tflat] = 0;
+        if (tile_work && lane == 0) tile_work[tflat] = 0;
         return;
     }
     int range_start, range_end;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void raster_item(
         }
         if (TRACK) last_ids[pix] = cur[k];
     }
-    if (tile_work && lane == 0 && sub == 0) tile_work[tflat] = walked;
+    if (tile_work && lane == 0) tile_work[tflat] = walked;     // halves: the later finisher's count stands
 }
 
 template <int CDIM, bool TRACK>
@@ -386,23 +386,45 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     //   map_mode 0: one contiguous band of tile rows per XCD (more L2 reuse of the gathered parameters; but
     //     the XCD that owns the dense band finishes long after the others: 0.49 vs 0.33 ms on the street scene,
     //     no difference on the uniform S-1M).
-    int tflat = blockIdx.x;
+    int tflat = blockIdx.x, kind = 0;
     if (order) {
-        tflat = order[blockIdx.x];
-        if ((unsigned)tflat >= (unsigned)total_tiles) return;
-    } else if (map_mode == 0) {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        // an ITEM of the dispatch list (include/street_crafter_amd.h, sc_tile_order_len): tile << 2 | kind, kind 0 =
+        // the whole tile, 1 / 2 = its upper / lower 16 x 8 half (two waves share a tile whose walk would otherwise be
+        // the launch's tail; quarters gained nothing more: profiles/r02_raster_split_ab.txt), negative = no work
+        const int item = order[blockIdx.x];
+        if (item < 0) return;
+        tflat = item >> 2;
+        kind = item & 3;
+        if (tflat >= total_tiles || kind == 3) return;
+    } else {
+        if (tflat >= total_tiles) return;
+        if (map_mode == 0) {
+            const int nwg = gridDim.x, bid = blockIdx.x;
+            const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+            tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
     }
-    raster_item<CDIM, TRACK, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
-                                tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
-                                render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s, tile_work);
+    if (kind == 0)
+        raster_item<CDIM, TRACK, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+                                    tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
+                                    render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s, tile_work);
+    else
+        raster_item<CDIM, TRACK, 2>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+                                    tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
+                                    render_colors, render_alphas, last_ids, dbg, tflat, kind - 1, xyoa_s, bck_s, col_s,
+                                    tile_work);
 }
 
 }  // namespace
 
 int g_sc_raster_map = 1;      // sc_set_option "raster_map": block -> tile map of the wave kernel (see there)
+int g_sc_raster_split = 50;   // sc_set_option "raster_split": tiles with >= this % of the heaviest tile's work are halved (0: none)
+
+// Length of a dispatch list for `total_tiles` tiles: every tile once, plus room for the tiles that are split into
+// halves (at most one in eight), padded with -1.
+extern "C" int sc_tile_order_len(int total_tiles) {
+    return total_tiles < 0 ? 0 : total_tiles + total_tiles / 8 + 8;
+}
 
 extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {
     (void)C; (void)tile_width; (void)tile_height;
@@ -434,9 +456,11 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     if (epilogue && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
     const int kdbg = g_sc_debug[1] | (epilogue ? 0x100 : 0);
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
+        if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
+        const int n_blocks = tile_order ? sc_tile_order_len(total_tiles) : total_tiles;
 #define SC_LAUNCH_WAVE(CD, TR)                                                                                      \
-    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(total_tiles), dim3(64), 0, sc_s(stream), means2d,        \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d,           \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
                        render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work)

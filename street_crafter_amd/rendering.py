@@ -308,7 +308,7 @@ def _isect_tiles_bin_locked(lib, means2d, radii, depths, C, N, tile_size, tile_w
     # what every tile walked the last time (tile_size 16: the wave-per-tile rasterizer)
     sched = None
     if _TILE_ORDER["on"] and int(tile_size) == 16:
-        sched = (torch.empty(C * tile_width * tile_height, dtype=torch.int32, device=dev),
+        sched = (torch.empty(lib.sc_tile_order_len(C * tile_width * tile_height), dtype=torch.int32, device=dev),
                  _tile_work(dev, C, tile_width, tile_height))
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
@@ -472,7 +472,8 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 def _sched_of(isect_offsets, n_tiles):
     """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
     sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
-    if sched is None or sched[0].numel() != n_tiles or sched[0].device != isect_offsets.device:
+    if (sched is None or sched[1].numel() != n_tiles or sched[0].device != isect_offsets.device
+            or sched[0].numel() != _lib.load().sc_tile_order_len(n_tiles)):
         return None, None
     return sched
 

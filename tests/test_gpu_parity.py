@@ -935,7 +935,7 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     work every tile reported the previous time.  Whatever the hint holds -- nothing (first frame), this scene
     (second frame) or a different scene of the same frame shape (stale) -- the order must be a permutation of
     the tiles and the image must be BIT-identical to the one rendered without it."""
-    from street_crafter_amd import rendering
+    from street_crafter_amd import _lib, rendering
     w, h = 640, 400
     cams = [make_camera(w, h, 600.0, 600.0, yaw=0.15 * i, shift=(0.4 * i, 0.0, 0.0)) for i in range(n_cams)]
     V = torch.stack([c.viewmat for c in cams]).to(DEV)
@@ -958,6 +958,7 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     n_tiles = n_cams * (w // 16) * (h // 16)
     rendering._TILE_WORK.clear()
     from scipy.ndimage import maximum_filter
+    split_counts = []
     for which in (0, 0, 1, 0):          # cold, warm, stale hint from scene 0, stale hint from scene 1
         torch.cuda.synchronize()
         hint = _np(rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), n_cams, w // 16, h // 16)).copy()
@@ -965,15 +966,33 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         order, work = meta["isect_offsets"]._sc_sched
         torch.cuda.synchronize()
         o = _np(order)
-        assert o.shape == (n_tiles,)
-        np.testing.assert_array_equal(np.sort(o), np.arange(n_tiles, dtype=np.int32))
+        assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
+        n_items = int((o >= 0).sum())
+        assert (o[:n_items] >= 0).all() and (o[n_items:] == -1).all()          # padding at the end only
+        tiles, kinds = o[:n_items] >> 2, o[:n_items] & 3
+        halves = tiles[kinds == 1]
+        # every tile once: whole, or as an upper and a lower half next to each other
+        np.testing.assert_array_equal(np.sort(np.concatenate([tiles[kinds == 0], halves])), np.arange(n_tiles))
+        first = np.nonzero(kinds == 1)[0]
+        assert (kinds[first + 1] == 2).all() and (tiles[first + 1] == halves).all() and (kinds == 3).sum() == 0
+        assert (kinds == 2).sum() == halves.size <= n_tiles // 8
         np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[which][0]).view(np.uint32))
         np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[which][1]).view(np.uint32))
         # heaviest first, by the class the order job files a tile under: the largest work within 2 tiles of it
-        # the previous time, in steps of 4 (isect_bin.hip, center_scatter_kernel block 2)
+        # the previous time, scaled so that the heaviest tile lands in the top classes of 1024
+        # (isect_bin.hip, center_scatter_kernel block 2)
         sm = maximum_filter(hint.reshape(n_cams, h // 16, w // 16), size=(1, 5, 5), mode="nearest").reshape(-1)
-        cls = 1023 - np.minimum(1023, sm >> 2)
-        assert (np.diff(cls[o]) >= 0).all()
+        shift = 0
+        while (int(hint.max()) >> shift) > 1023:
+            shift += 1
+        cls = 1023 - np.minimum(1023, sm >> shift)
+        assert (np.diff(cls[tiles]) >= 0).all()
+        # halved: only tiles within a factor 2 of the heaviest, heaviest classes first
+        if halves.size:
+            assert hint.max() >= 32
+            assert (cls[halves] <= 1023 - ((int(hint.max()) * 50 // 100) >> shift)).all()
+            assert cls[halves].max() <= cls[tiles[kinds == 0]].min()
+        split_counts.append(halves.size)
         # what the kernel reported: entries walked (+8 per staged batch), zero exactly where the tile list is empty
         offs = _np(meta["isect_offsets"]).reshape(-1).astype(np.int64)
         counts = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
@@ -981,6 +1000,16 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         assert ((wk == 0) == (counts == 0)).all()
         assert (wk <= counts + 8 * ((counts + 63) // 64 + 1)).all()
         assert wk.max() > 50
+    assert split_counts[0] == 0 and max(split_counts[1:]) > 0          # no hint: nothing is split
+    prev = _lib.set_option("raster_split", 0)
+    try:
+        rc, ra, meta = render(scenes[0])
+        o = _np(meta["isect_offsets"]._sc_sched[0])
+    finally:
+        _lib.set_option("raster_split", prev)
+    assert ((o[:n_tiles] & 3) == 0).all() and (o[n_tiles:] == -1).all()
+    np.testing.assert_array_equal(np.sort(o[:n_tiles] >> 2), np.arange(n_tiles))
+    np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0][0]).view(np.uint32))
 
 
 def test_tile_dispatch_order_in_training(ops):
