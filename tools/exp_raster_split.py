@@ -52,26 +52,25 @@ def timeit(order=None):
     return ts[len(ts) // 2] * 1e3
 
 
-def items(wk, thr, cap, qthr=2.0):
-    """tiles with work >= thr * max are split into halves (>= qthr * max: quarters), at most `cap` extra items;
-    parts keep their tile's place in the heaviest-first order"""
+def items(wk, thr, cap):
+    """tiles with work >= thr * max are listed as two halves, at most `cap` of them; the halves are adjacent and keep
+    their tile's place in the heaviest-first order (what the order job of isect_bin.hip builds)"""
     wk = wk.to(torch.float32)
     order = torch.argsort(wk, descending=True, stable=True)
     ws = wk[order]
     parts = torch.ones(T, dtype=torch.int64, device="cuda")
     parts[ws >= thr * wk.max()] = 2
-    parts[ws >= qthr * wk.max()] = 4
     extra = torch.cumsum(parts - 1, 0)
     parts[extra > cap] = 1                                  # out of room: the lighter ones stay whole
     rep = torch.repeat_interleave(order, parts)
     first = torch.cumsum(parts, 0) - parts
     sub = torch.arange(rep.numel(), device="cuda") - torch.repeat_interleave(first, parts)
     np_ = torch.repeat_interleave(parts, parts)
-    kind = torch.where(np_ == 1, 0, torch.where(np_ == 2, 1 + sub, 3 + sub))
-    it = ((rep << 3) | kind).to(torch.int32)
+    kind = torch.where(np_ == 1, 0, 1 + sub)
+    it = ((rep << 2) | kind).to(torch.int32)
     out = torch.full((L,), -1, dtype=torch.int32, device="cuda")
     out[: it.numel()] = it
-    return out, int((parts == 2).sum()), int((parts == 4).sum())
+    return out, int((parts == 2).sum())
 
 
 def items_sorted(wk, thr, cap, half_weight):
@@ -82,7 +81,7 @@ def items_sorted(wk, thr, cap, half_weight):
         idx = torch.argsort(wk, descending=True)[:cap]
         split = torch.zeros_like(split); split[idx] = True
     t = torch.arange(T, device="cuda", dtype=torch.int32)
-    it = torch.cat([t[~split] << 3, (t[split] << 3) | 1, (t[split] << 3) | 2])
+    it = torch.cat([t[~split] << 2, (t[split] << 2) | 1, (t[split] << 2) | 2])
     wt = torch.cat([wk[~split], wk[split] * half_weight, wk[split] * half_weight])
     it = it[torch.argsort(wt, descending=True, stable=True)]
     out = torch.full((L,), -1, dtype=torch.int32, device="cuda")
@@ -96,16 +95,32 @@ ref = rc.clone()
 w = work.clone()
 print(which, "work per tile: mean %.0f p50 %.0f p99 %.0f max %d; I=%d" % (w.float().mean(), w.float().median(),
       w.float().quantile(0.99), int(w.max()), fids.numel()))
-cands = [("no list", None)]
-for cap in (T // 8, T // 4):
-    for thr in (0.7, 0.6, 0.5):
-        cands.append((f"cap {cap} thr {thr} adjacent parts", items(w, thr, cap)[0]))
-        cands.append((f"cap {cap} thr {thr} sorted, half weight 1.0", items_sorted(w, thr, cap, 1.0)))
-        cands.append((f"cap {cap} thr {thr} sorted, half weight 0.65", items_sorted(w, thr, cap, 0.65)))
+cap = L - T
+nlist = torch.diff(torch.cat([off.view(-1), torch.tensor([fids.numel()], dtype=torch.int32, device="cuda")]))
+print("  list length vs work: corr %.3f" % float(torch.corrcoef(torch.stack([nlist.float(), w.float()]))[0, 1]))
+cands = [("no list (tile = block)", None), ("heaviest first, whole tiles", items(w, 2.0, cap)[0]),
+         ("longest list first, whole tiles", items(nlist, 2.0, cap)[0])]
+for thr in (0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3):
+    o, n = items(w, thr, cap)
+    cands.append((f"halves >= {thr:.1f} x max ({n} tiles), adjacent", o))
+cands.append(("halves >= 0.5 x max, sorted apart, half weight 1.0", items_sorted(w, 0.5, cap, 1.0)))
+cands.append(("halves >= 0.5 x max, sorted apart, half weight 0.65", items_sorted(w, 0.5, cap, 0.65)))
+def tail_halves(k):
+    """tile order, the LAST k tiles as halves (no hint needed: smaller items at the end of the launch)"""
+    t = torch.arange(T, device="cuda", dtype=torch.int32)
+    head, tl = t[: T - k] << 2, t[T - k:]
+    it = torch.cat([head, torch.stack([(tl << 2) | 1, (tl << 2) | 2], 1).reshape(-1)])
+    out = torch.full((L,), -1, dtype=torch.int32, device="cuda")
+    out[: it.numel()] = it
+    return out
+
+
+for k in (300, 600, 1200):
+    cands.append((f"tile order, last {k} tiles as halves", tail_halves(k)))
 res = {n: [] for n, _ in cands}
-for rnd in range(3):
+for rnd in range(4):                      # round 0 = warm-up (clocks), not shown
     for n, o in cands:
         res[n].append(timeit(o))
 for n, o in cands:
     launch(o); torch.cuda.synchronize()
-    print(f"  {n:50s} " + " ".join(f"{t:7.1f}" for t in res[n]) + f"  identical={bool(torch.equal(rc, ref))}")
+    print(f"  {n:55s} " + " ".join(f"{t:7.1f}" for t in res[n][1:]) + f" us  identical={bool(torch.equal(rc, ref))}")

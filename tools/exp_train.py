@@ -43,6 +43,11 @@ def step():
 from street_crafter_amd import _lib  # noqa: E402
 if os.environ.get("SC_RASTER_BWD"):
     _lib.set_option("raster_bwd", int(os.environ["SC_RASTER_BWD"]))
+if os.environ.get("SC_TILE_ORDER"):
+    from street_crafter_amd import rendering
+    rendering.set_tile_order(bool(int(os.environ["SC_TILE_ORDER"])))
+if os.environ.get("SC_RASTER_SPLIT"):
+    _lib.set_option("raster_split", int(os.environ["SC_RASTER_SPLIT"]))
 for _ in range(3):
     step()
 torch.cuda.synchronize()
