@@ -258,6 +258,8 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
  *                     8 XCDs (default), 0 = one band of tile rows per XCD
  *   key "raster_split": 0..100: the dispatch list sc_isect_bin_count builds lists a tile as two 16 x 8 halves when
  *                     its work hint is at least this percentage of the heaviest tile's (default 50; 0 = never)
+ *   key "raster_hint_blend": 0..4: a tile's work hint = max(its own, this many quarters of the largest hint within
+ *                     2 tiles of it) (default 3; 0 = own value only: exact for a camera that stands still)
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)

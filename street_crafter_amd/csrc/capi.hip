@@ -40,6 +40,12 @@ extern "C" int sc_set_option(const char* key, int value) {
         g_sc_raster_map = value;
         return prev;
     }
+    if (strcmp(key, "raster_hint_blend") == 0) {
+        if (value < 0 || value > 4) return SC_EINVAL;
+        const int prev = g_sc_raster_hint_blend;
+        g_sc_raster_hint_blend = value;
+        return prev;
+    }
     if (strcmp(key, "raster_split") == 0) {
         if (value < 0 || value > 100) return SC_EINVAL;
         const int prev = g_sc_raster_split;

@@ -295,43 +295,98 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         // (tools/exp_raster_split.py).  Counting sort over 1024 classes of work, heaviest class first; the order
         // inside a class is whatever the atomics give (tile order and random order time the same).
         if (!tile_order) return;
+        // This ONE workgroup must stay shorter than the centre workgroups beside it (~20 us): 16-bit LDS tables, a
+        // separable 5 x 5 maximum, tile coordinates advanced without divisions, run-aggregated LDS atomics.
         unsigned* cls = lds;                 // [1024]
-        unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles]: class of every tile
-        int* wk = reinterpret_cast<int*>(lds + 1024) + (n_tiles_total + 1) / 2;    // [tiles] snapshot of tile_work (smooth only)
+        const int tpad = (n_tiles_total + 1) & ~1;
+        unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles] class of every tile
+        unsigned short* wk = snap + tpad;    // [tiles] snapshot of tile_work, saturated to 16 bits
+        unsigned short* hm = wk + tpad;      // [tiles] its maximum over x - 2 .. x + 2            (both: smooth only)
         __shared__ int s_lim, s_nsplit;
         const int n_items_max = n_tiles_total + n_tiles_total / 8 + 8;             // == sc_tile_order_len
         const int cap = n_tiles_total / 8;
+        const int lane = sc_lane();
         cls[threadIdx.x] = 0;
         if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; }
+        // (tile, row, camera) of a thread's k-th tile, i = threadIdx.x + k * BIN_THREADS, without divisions in the loops
+        const int tw = g.tile_width, th = g.tile_height;
+        const int step_x = BIN_THREADS % tw, step_y = BIN_THREADS / tw;
+        struct Pos { int tx, ty; };
+        auto first_pos = [&]() { const int rem = (int)threadIdx.x % g.T; return Pos{rem % tw, rem / tw}; };
+        auto advance = [&](Pos& p) {
+            p.tx += step_x; p.ty += step_y;
+            if (p.tx >= tw) { p.tx -= tw; ++p.ty; }
+            while (p.ty >= th) p.ty -= th;                     // next camera: rows start again
+        };
         // tile_work may be written by another stream's rasterizer right now: every value that decides a tile's
-        // place is read ONCE (the passes below must agree, or a tile would be listed twice or not at all)
+        // place is read ONCE (the sweeps below must agree, or a tile would be listed twice or not at all)
         unsigned lmax = 0;
+        long long lsum = 0;
         for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
-            const int w = tile_work ? max(tile_work[i], 0) : 0;
-            if (smooth) wk[i] = w;
+            const int w = tile_work ? min(max(tile_work[i], 0), 65535) : 0;
+            if (smooth) wk[i] = (unsigned short)w;
+            else snap[i] = (unsigned short)w;                   // (becomes the class below)
             lmax = max(lmax, (unsigned)w);
+            lsum += w;
         }
-        long long tot;
+        long long tot, wsum;
         unsigned wmax;
-        block_scan_1024(0, lmax, &tot, &wmax, wave_tot, wave_max);     // (syncs: the snapshot is complete)
+        block_scan_1024(lsum, lmax, &wsum, &wmax, wave_tot, wave_max);     // (syncs: the snapshot is complete)
+        // halving pays when a few tiles stand far above the rest (street scene: heaviest 7x the mean, -70 us); on
+        // an even frame (S-1M: 1.7x) it only adds the halves' second staging (+3 us): ask for 3x the mean
+        const bool skewed = (long long)wmax * n_tiles_total >= 3 * wsum;
         int shift = 0;
         while ((wmax >> shift) > 1023u) ++shift;
-        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
-            int w = 0;
-            if (smooth) {
-                // the hint is one or two frames old and the camera has moved: a tile inherits the largest work
-                // within 2 tiles of it (a per-frame jitter of 40 px made the plain per-tile hint useless on S-1M)
-                const int cam = i / g.T, rem = i - cam * g.T;
-                const int ty = rem / g.tile_width, tx = rem - ty * g.tile_width;
-                for (int yy = max(ty - 2, 0); yy <= min(ty + 2, g.tile_height - 1); ++yy)
-                    for (int xx = max(tx - 2, 0); xx <= min(tx + 2, g.tile_width - 1); ++xx)
-                        w = max(w, wk[cam * g.T + yy * g.tile_width + xx]);
-            } else if (tile_work) {
-                w = max(tile_work[i], 0);
+        if (smooth) {
+            Pos p = first_pos();
+            for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS, advance(p)) {
+                const unsigned short* row = wk + (i - p.tx);
+                unsigned m = row[p.tx];
+                if (p.tx >= 1) m = max(m, (unsigned)row[p.tx - 1]);
+                if (p.tx >= 2) m = max(m, (unsigned)row[p.tx - 2]);
+                if (p.tx + 1 < tw) m = max(m, (unsigned)row[p.tx + 1]);
+                if (p.tx + 2 < tw) m = max(m, (unsigned)row[p.tx + 2]);
+                hm[i] = (unsigned short)m;
             }
-            const int c = 1023 - min(1023, w >> shift);
-            snap[i] = (unsigned short)c;
-            atomicAdd(&cls[c], 1u);
+            __syncthreads();
+        }
+        // (the smoothed hint has plateaus: neighbouring tiles = neighbouring lanes share a class, and 64 lanes adding
+        // to one LDS counter serialise.  A RUN of equal classes among consecutive lanes is added by its first lane
+        // alone, in both sweeps.)
+        auto run_of = [&](int c, int* head_lane, int* len) {
+            const int prev = __shfl_up(c, 1, 64);
+            const unsigned long long heads = __ballot(lane == 0 || c != prev);
+            const unsigned long long rest = lane == 63 ? 0ull : heads >> (lane + 1);
+            *len = rest ? __ffsll((long long)rest) : 64 - lane;               // meaningful on head lanes
+            *head_lane = 63 - __clzll((long long)(heads & (sc_lanemask_lt() | (1ull << lane))));
+        };
+        const int n_round = (n_tiles_total + 63) & ~63;                       // whole waves take part in the votes
+        {
+            Pos p = first_pos();
+            for (int i = threadIdx.x; i < n_round; i += BIN_THREADS, advance(p)) {
+                int c = -1;
+                if (i < n_tiles_total) {
+                    unsigned w;
+                    if (smooth) {
+                        // the hint is one or two frames old and the camera has moved since: a tile is filed under
+                        // the larger of its own work and smooth/4 (default 3/4) of the largest work within 2 tiles of it (own value:
+                        // exact for a camera that stands still; neighbourhood: a heavy region that has moved on)
+                        unsigned m = hm[i];
+                        if (p.ty >= 1) m = max(m, (unsigned)hm[i - tw]);
+                        if (p.ty >= 2) m = max(m, (unsigned)hm[i - 2 * tw]);
+                        if (p.ty + 1 < th) m = max(m, (unsigned)hm[i + tw]);
+                        if (p.ty + 2 < th) m = max(m, (unsigned)hm[i + 2 * tw]);
+                        w = max((unsigned)wk[i], (m * (unsigned)smooth) >> 2);
+                    } else {
+                        w = snap[i];
+                    }
+                    c = 1023 - (int)min(1023u, w >> shift);
+                    snap[i] = (unsigned short)c;
+                }
+                int hl, len;
+                run_of(c, &hl, &len);
+                if (hl == lane && c >= 0) atomicAdd(&cls[c], (unsigned)len);
+            }
         }
         __syncthreads();
         const unsigned cnt = cls[threadIdx.x];
@@ -340,19 +395,24 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         // classes [0, lim) are split: those whose work is at least split_pct % of the heaviest tile's, as far as
         // the list has room (heavier classes first, whole classes only)
         const int c_split = 1023 - (int)((((unsigned long long)wmax * (unsigned)split_pct) / 100u) >> shift);
-        const bool mine = split_pct > 0 && wmax >= 32u && (int)threadIdx.x <= c_split && run + cnt <= cap;
+        const bool mine = split_pct > 0 && wmax >= 32u && skewed && (int)threadIdx.x <= c_split && run + cnt <= cap;
         if (mine) { atomicAdd(&s_lim, 1); atomicMax(&s_nsplit, (int)(run + cnt)); }
         __syncthreads();
         const int lim = s_lim, n_split = s_nsplit;       // `mine` holds on a prefix of the classes
         cls[threadIdx.x] = (int)threadIdx.x < lim ? (unsigned)(2 * run) : (unsigned)(run + n_split);
         __syncthreads();
-        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
-            const int c = snap[i];
-            if (c < lim) {
-                const unsigned slot = atomicAdd(&cls[c], 2u);
+        for (int i = threadIdx.x; i < n_round; i += BIN_THREADS) {
+            const int c = i < n_tiles_total ? (int)snap[i] : -1;
+            int hl, len;
+            run_of(c, &hl, &len);
+            const unsigned parts = c < lim ? 2u : 1u;
+            unsigned slot = 0;
+            if (hl == lane && c >= 0) slot = atomicAdd(&cls[c], (unsigned)len * parts);
+            slot = (unsigned)__shfl((int)slot, hl, 64) + (unsigned)(lane - hl) * parts;
+            if (c < 0) continue;
+            if (parts == 2u) {
                 if (slot + 1 < (unsigned)n_items_max) { tile_order[slot] = i << 2 | 1; tile_order[slot + 1] = i << 2 | 2; }
             } else {
-                const unsigned slot = atomicAdd(&cls[c], 1u);
                 if (slot < (unsigned)n_items_max) tile_order[slot] = i << 2;
             }
         }
@@ -1265,8 +1325,8 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     unsigned* scans_done = (unsigned*)(ws + L.scans_done);
     size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
     // the order job: 1024 class counters + a class per tile (+ a snapshot of tile_work for the smoothed hint)
-    const int smooth = tile_order && tile_work && 4096 + (size_t)L.ntb * 6 + 8 <= 150 * 1024;
-    const size_t order_lds = 4096 + (size_t)L.ntb * (smooth ? 6 : 2) + 8;
+    const int smooth = (tile_order && tile_work && 4096 + (size_t)L.ntb * 6 + 16 <= 150 * 1024) ? g_sc_raster_hint_blend : 0;
+    const size_t order_lds = 4096 + ((size_t)L.ntb + 1) * (smooth ? 6 : 2) + 16;
     if (tile_order && center_lds < order_lds) center_lds = order_lds;
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 3), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,

@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
 }  // namespace
 
 int g_sc_raster_map = 1;      // sc_set_option "raster_map": block -> tile map of the wave kernel (see there)
+int g_sc_raster_hint_blend = 3;   // sc_set_option "raster_hint_blend": weight (quarters) of the +-2 tile neighbourhood maximum in a tile's hint
 int g_sc_raster_split = 50;   // sc_set_option "raster_split": tiles with >= this % of the heaviest tile's work are halved (0: none)
 
 // Length of a dispatch list for `total_tiles` tiles: every tile once, plus room for the tiles that are split into

@@ -24,6 +24,7 @@
 // that is derived from the skipped producer IN BOUNDS for every consumer -- skip stores, never the
 // computation of counts / offsets other code indexes with, and bound-check at the consumer anyway.
 extern int g_sc_debug[4];
+extern int g_sc_raster_hint_blend;   // sc_set_option "raster_hint_blend"
 extern int g_sc_raster_split;   // sc_set_option "raster_split" (raster_fwd.hip; read by the order job of isect_bin.hip)
 
 static inline hipStream_t sc_s(sc_stream_t s) { return (hipStream_t)s; }
