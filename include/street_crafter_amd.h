@@ -50,6 +50,10 @@ const char* sc_version(void);
 const char* sc_error_string(int code);
 /* compiled-for architecture string, e.g. "gfx950" */
 const char* sc_target_arch(void);
+/* host-side spin until *addr == value (acquire); returns 0, or 1 after timeout_us microseconds (< 0: never).
+ * For the sequence number sc_isect_bin_count publishes into host-mapped memory (meta_mirror[4]); a ctypes host
+ * calls it without holding the GIL, so other host threads keep launching meanwhile. */
+int sc_wait_i64(const int64_t* addr, int64_t value, int64_t timeout_us);
 
 /* ---- a1: projection (renderer.py:219-232) -------------------------------------------- */
 int sc_projection_fwd(const float* means, const float* quats, const float* scales,

@@ -25,6 +25,7 @@ c_stream = C.c_void_p
 SIGNATURES = {
     "sc_version": (C.c_char_p, []),
     "sc_error_string": (C.c_char_p, [C.c_int]),
+    "sc_wait_i64": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "sc_target_arch": (C.c_char_p, []),
     "sc_projection_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, c_i32p, c_f32p,

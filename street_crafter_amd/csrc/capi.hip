@@ -1,6 +1,7 @@
 // Library-level entry points of the C ABI (include/street_crafter_amd.h).
 #include "raster_common.h"
 #include <string.h>
+#include <time.h>
 
 extern "C" const char* sc_version(void) { return "street_crafter_amd 0.1.0 (gfx950)"; }
 
@@ -19,6 +20,27 @@ extern "C" const char* sc_error_string(int code) {
 }
 
 int g_sc_debug[4] = {0, 0, 0, 0};
+
+// Host-side wait for the sequence number that center_scatter_kernel publishes behind the frame's sizes
+// (host-mapped pinned memory, include/street_crafter_amd.h sc_isect_bin_count).  A plain spin in C: a Python host
+// calls it through ctypes.CDLL, which releases the GIL for the duration, so a second host thread (the other frame
+// in flight) keeps launching while this one waits for its counts.
+extern "C" int sc_wait_i64(const int64_t* addr, int64_t value, int64_t timeout_us) {
+    if (!addr) return SC_EINVAL;
+    struct timespec t0;
+    bool have_t0 = false;
+    for (unsigned spins = 1;; ++spins) {
+        if (__atomic_load_n(addr, __ATOMIC_ACQUIRE) == value) return SC_OK;
+        __builtin_ia32_pause();
+        if ((spins & 1023u) == 0) {
+            struct timespec now;
+            clock_gettime(CLOCK_MONOTONIC, &now);
+            if (!have_t0) { t0 = now; have_t0 = true; }
+            const int64_t us = (int64_t)(now.tv_sec - t0.tv_sec) * 1000000 + (now.tv_nsec - t0.tv_nsec) / 1000;
+            if (timeout_us >= 0 && us > timeout_us) return 1;       // timed out (not an error code of the library)
+        }
+    }
+}
 
 extern "C" int sc_set_option(const char* key, int value) {
     if (!key) return SC_EINVAL;

@@ -241,7 +241,6 @@ _BIN_PREDICTION = {}
 _TILE_WORK = {}        # (device index, C, tile_width, tile_height) -> int32 [C * tiles]: the list entries every tile
                        # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
 _TILE_ORDER = {"on": True}
-_BIN_LOCK = threading.Lock()     # the pinned meta slot + sequence number below are per device, not per thread
 _LAZY_ISECT_IDS = {"on": True}
 
 
@@ -268,7 +267,8 @@ def set_lazy_isect_ids(enabled: bool) -> bool:
     return prev
 
 _BIN_LAST_META = {}    # same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
-_PINNED_META = {}      # device index -> [pinned int64[8] the device publishes meta into, its numpy view, seq]
+_PINNED_META = threading.local()   # .slots: device index -> [pinned int64[8] the device publishes meta into, its
+                                   # numpy view, seq] of THIS host thread
 
 
 def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
@@ -279,28 +279,27 @@ def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
     return n_isects <= capacities[0] and n_records <= capacities[1] and max_super <= capacities[2]
 
 
-def _isect_tiles_bin(*args, **kwargs):
+def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
+                     tiles_per_gauss, total_dev, st, want_ids=True):
     """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
     the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
-    rasterization() forward never reads it).  Host threads are serialised: the count phase reports its sizes
-    through ONE pinned slot + sequence number per device (several frames in flight from one thread are fine:
-    the host handles them one after the other)."""
-    with _BIN_LOCK:
-        return _isect_tiles_bin_locked(*args, **kwargs)
-
-
-def _isect_tiles_bin_locked(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                            tiles_per_gauss, total_dev, st, want_ids=True):
+    rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
+    its sizes through a pinned slot + sequence number per (host thread, device), and the wait for it releases
+    the GIL (sc_wait_i64) -- a host that renders two frames in flight from two threads keeps launching one frame
+    while it waits for the other's counts (dist.render_sharded(host_threads=True))."""
     dev = means2d.device
     offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
     meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
     ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
     # meta (output sizes) comes back through host-mapped pinned memory that the device writes
     # directly, followed by a sequence number: no D2H copy and no event on the stream (include/*.h)
-    slot = _PINNED_META.get(dev.index)
+    slots = getattr(_PINNED_META, "slots", None)
+    if slots is None:
+        slots = _PINNED_META.slots = {}
+    slot = slots.get(dev.index)
     if slot is None:
         host = torch.zeros(8, dtype=torch.int64, pin_memory=True)
-        slot = _PINNED_META[dev.index] = [host, host.numpy(), 0]
+        slot = slots[dev.index] = [host, host.numpy(), 0]
     meta_host, meta_np = slot[0], slot[1]
     slot[2] += 1
     seq = slot[2]
@@ -321,18 +320,10 @@ def _isect_tiles_bin_locked(lib, means2d, radii, depths, C, N, tile_size, tile_w
     _lib.check(rc, "sc_isect_bin_count")
 
     def read_meta():
-        # poll the sequence number; if the GPU is far behind (or something went wrong) fall back to a
-        # plain synchronising copy after ~2 s
-        deadline = None
-        spins = 0
-        while meta_np[4] != seq:
-            spins += 1
-            if spins % 4096 == 0:
-                now = time.monotonic()
-                if deadline is None:
-                    deadline = now + 2.0
-                elif now > deadline:
-                    return tuple(int(v) for v in meta_dev.cpu().tolist())
+        # wait for the sequence number (a spin in C that holds no GIL); if the GPU is far behind (or something went
+        # wrong) fall back to a plain synchronising copy after 2 s
+        if lib.sc_wait_i64(meta_host.data_ptr() + 32, seq, 2_000_000) != 0:
+            return tuple(int(v) for v in meta_dev.cpu().tolist())
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
     eager_ids = want_ids and not _LAZY_ISECT_IDS["on"]
