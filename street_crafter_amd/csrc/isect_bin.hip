@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(BS_THREADS) void big_split_kernel(
             lo = red_lo[w] < lo ? red_lo[w] : lo;
             hi = red_hi[w] > hi ? red_hi[w] : hi;
         }
+        if (dbg & 8) continue;                      // diagnostic: price the min / max pass alone (no segments are made)
         const double sc = (double)BS_NB / ((double)(hi - lo) + 1.0);
         auto bin_of = [&](unsigned long long K) -> int {
             const int b = (int)((double)(K - lo) * sc);
@@ -1075,6 +1076,7 @@ __global__ __launch_bounds__(BS_THREADS) void big_split_kernel(
         };
         for_records(src, n, [&](uint2 rc) { atomicAdd(&hist[bin_of(rec_key60(rc)) * REP + (lane & (REP - 1))], 1u); });
         __syncthreads();
+        if (dbg & 16) continue;                     // diagnostic: ... and the histogram pass
         // thread t owns bin t.  light = exclusive prefix of the light bins' counts, H = heavy bins before t.
         unsigned c = 0;
 #pragma unroll

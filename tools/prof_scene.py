@@ -24,6 +24,10 @@ elif which == "sky":
 else:
     raise SystemExit(__doc__)
 sc = sc.to("cuda")
+for k in range(4):
+    if os.environ.get(f"SC_DEBUG{k}"):
+        from street_crafter_amd import _lib
+        _lib.set_option(f"debug{k}", int(os.environ[f"SC_DEBUG{k}"]))
 cam = make_camera().to("cuda")
 with torch.no_grad():
     for _ in range(frames):
