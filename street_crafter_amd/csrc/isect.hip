@@ -209,7 +209,7 @@ extern "C" int sc_isect_emit(const float* means2d, const int32_t* radii, const f
     if (CN == 0 || n_isects == 0) return SC_OK;
     if (!means2d || !radii || !depths || !isect_ids || !flatten_ids || !workspace) return SC_EINVAL;
     if (ws_bytes < sc_isect_workspace_bytes(CN)) return SC_EWORKSPACE;
-    if (CN > 0x7fffffff) return SC_EINVAL;  // flatten_ids are int32
+    if (CN > 0x7fffffff || n_isects > 0x7fffffffLL) return SC_EINVAL;  // flatten_ids and the offsets into them are int32
     const int64_t nb = isect_num_blocks(CN);
     const int tile_bits = sc_bits_for((int64_t)tile_width * tile_height);
     hipLaunchKernelGGL(isect_emit_kernel, dim3((unsigned)nb), dim3(BLK), 0, sc_s(stream), means2d,

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     tab.base[lane] = cam_base; tab.off[lane] = off; tab.depth[lane] = depth; tab.id[lane] = id;
     for (int q = 0; q < c; ++q) tab.owner[off + q] = (unsigned char)lane;
     __syncthreads();                       // hist zeroed, tables complete
+    if (dbg & 4) return;                   // diagnostic: price the load + table build alone
 
     // decode pair number p -> bucket (and, for pass 2, everything the record needs)
     auto bucket_of = [&](int p, int& o, int& sx, int& sy) -> int {
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     }
     walk_big([&](int b, const Rect&, int, int, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     __syncthreads();
+    if (dbg & 8) return;                   // diagnostic: ... and the counting pass
     for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) {
         const unsigned cb = hist[b];
         if (cb) gbase[b] = (unsigned)soffsets[b] + atomicAdd(&cursor[b], cb);

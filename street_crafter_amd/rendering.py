@@ -214,6 +214,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                   int(tile_height), _p(tiles_per_gauss), _p(total_dev), _p(ws), ws.numel(), st),
                "sc_isect_count")
     n_isects = int(total_dev.item())    # the one unavoidable D2H read (sizes the outputs)
+    _check_isect_count(n_isects, C, N, tile_width, tile_height)
     isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     if n_isects:
@@ -231,6 +232,14 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                                        n_isects, 32 + tile_bits + cam_bits, _p(sws),
                                                        sws.numel(), st), "sc_radix_sort_pairs_u64_i32")
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+def _check_isect_count(n_isects, C, N, tile_width, tile_height):
+    """isect_offsets / positions in flatten_ids are int32, as in gsplat (which wraps around silently here)."""
+    if n_isects > 0x7fffffff:
+        raise RuntimeError(f"isect_tiles: {n_isects} tile intersections exceed the int32 range of isect_offsets "
+                           f"({C} cameras x {N} Gaussians on {tile_width}x{tile_height} tiles); render fewer "
+                           "cameras per call or cull the scene")
 
 
 # Sizes seen on the previous call with the same shape: lets the bucket scatter + per-tile sort be
@@ -347,6 +356,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         elif rc != 0:
             _lib.check(rc, "sc_isect_bin_sort")
     n_isects, _, n_records, max_super = read_meta()     # the one host wait of a frame; GPU already has work
+    _check_isect_count(n_isects, C, N, tile_width, tile_height)
     # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
     # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
     if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):

@@ -362,6 +362,26 @@ def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
     assert rendering._bin_launch_ran((10, 10, 10), 10, 10, 10) and not rendering._bin_launch_ran((10, 10, 10), 10, 10, 11)
 
 
+@pytest.mark.parametrize("mode", ["radix", "bin"])
+def test_isect_refuses_more_than_int32_intersections(ops, mode):
+    """isect_offsets and the positions in flatten_ids are int32 (as in gsplat, which wraps around silently):
+    a call that would produce more than 2^31 - 1 intersections fails loudly after the count pass, before
+    anything is allocated for them -- on both routes."""
+    from street_crafter_amd import rendering
+    tw, th = 160, 74                       # 11 840 tiles
+    n = 200_000                            # every splat covers the whole frame: 2.37e9 intersections
+    m2 = torch.full((1, n, 2), 600.0, device=DEV)
+    r = torch.full((1, n), 100_000, dtype=torch.int32, device=DEV)
+    d = torch.rand(1, n, device=DEV) + 1.0
+    prev = rendering.set_isect_mode(mode)
+    try:
+        with pytest.raises(RuntimeError, match="exceed the int32 range"):
+            ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)
+    finally:
+        rendering.set_isect_mode(prev)
+    assert torch.cuda.memory_allocated() < 2 << 30
+
+
 def test_radix_sort_large_stable(ops):
     """4.2 M pairs with heavy key duplication vs torch.sort(stable=True) (same device)."""
     from street_crafter_amd import _lib

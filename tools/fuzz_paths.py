@@ -43,14 +43,23 @@ for it in range(ROUNDS):
                                                            near_plane=0.001, far_plane=1000.0, calc_compensations=True)
         tw, th = (W + 15) // 16, (H + 15) // 16
         outs = {}
+        too_many = False
         for mode in ("bin", "radix"):
             prev = rendering.set_isect_mode(mode)
             try:
                 tpg, ids, fids = R.isect_tiles(m2, radii, d, 16, tw, th, n_cameras=C)
                 off = R.isect_offset_encode(ids, C, tw, th)
+            except RuntimeError as e:          # big splats x many tiles: beyond int32 intersections, refused loudly
+                if "exceed the int32 range" not in str(e):
+                    raise
+                too_many = True
+                break
             finally:
                 rendering.set_isect_mode(prev)
             outs[mode] = (tpg, ids, fids, off)
+        if too_many:
+            print(f"[{it}] N={n} C={C} {W}x{H} smax={smax} z>={zmin}: more than 2^31 - 1 intersections, refused by both routes", flush=True)
+            continue
         ok_isect = all(torch.equal(a, b) for a, b in zip(outs["bin"], outs["radix"]))
         op = sc.opacities[None, :, 0] * comp
         cols = torch.rand(C, n, 4, device="cuda")
