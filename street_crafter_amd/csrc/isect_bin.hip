@@ -478,11 +478,9 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
 // Slots: per-workgroup LDS histogram, one global atomic per (workgroup, touched bucket), LDS cursors.
 constexpr int FLAT_THREADS = 512;                // A/B on S-1M: 256 -> 52 us, 512 -> 47, 1024 -> 51
 constexpr int FLAT_THREADS_SMALL = 128;          // <= 262144 Gaussians: 2 waves x 16 Gaussians per workgroup
-struct FlatTab {                 // per wave
-    int rx0[64], rx1[64], ry0[64], ry1[64];        // tile rectangle (for the 2x2 tile mask)
-    int sx0[64], sy0[64], sw[64], inv[64];         // super-tile rectangle origin, width, 65536 / width + 1
-    int base[64], off[64];                         // camera bucket base, first pair number
-    unsigned depth[64], id[64];
+struct FlatTab {                 // per wave; one 16-B LDS read per table and pair (they were 12 separate arrays)
+    uint4 a[64];     // super-tile rectangle: x0 | y0 << 16, (65536 / width + 1) | width << 20, first pair number, camera bucket base
+    uint4 b[64];     // the Gaussian's payload as center_scatter wrote it: tile x0 | x1 << 16, y0 | y1 << 16, depth bits, id
     unsigned char owner[64 * BIN_BIG];             // pair number -> lane
 };
 
@@ -504,7 +502,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     unsigned* hist = lds;                  // [n_sbuckets] counts, then running local cursors
     unsigned* gbase = lds + n_sbuckets;    // [n_sbuckets] global start of this workgroup's slice
     const int lane = sc_lane(), wave = threadIdx.x >> 6;
-    FlatTab& tab = reinterpret_cast<FlatTab*>(lds + 2 * n_sbuckets)[wave];
+    FlatTab& tab = reinterpret_cast<FlatTab*>(lds + ((2 * n_sbuckets + 3) & ~3))[wave];      // 16-B aligned
     for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) hist[b] = 0;
 
     // consecutive lanes take consecutive Gaussians of the spatial order
@@ -512,8 +510,9 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     Rect r = {0, 0, 0, 0}, sr = {0, 0, 0, 0};
     int cam_base = 0;
     unsigned depth = 0, id = 0;
+    uint4 pay = make_uint4(0u, 0u, 0u, 0u);
     if (lane < GPW && j < M) {
-        const uint4 pay = sorted[j];
+        pay = sorted[j];
         r.x0 = (int)(pay.x & 0xffffu); r.x1 = (int)(pay.x >> 16);
         r.y0 = (int)(pay.y & 0xffffu); r.y1 = (int)(pay.y >> 16);
         depth = pay.z;
@@ -527,10 +526,11 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     const int incl = sc_wave_incl_scan(c);
     const int off = incl - c;
     const int T = __builtin_amdgcn_readlane(incl, 63);
-    tab.rx0[lane] = r.x0; tab.rx1[lane] = r.x1; tab.ry0[lane] = r.y0; tab.ry1[lane] = r.y1;
-    tab.sx0[lane] = sr.x0; tab.sy0[lane] = sr.y0; tab.sw[lane] = sw;
-    tab.inv[lane] = sw > 0 ? 65536 / sw + 1 : 0;              // q / sw == (q * inv) >> 16 for q < 1024
-    tab.base[lane] = cam_base; tab.off[lane] = off; tab.depth[lane] = depth; tab.id[lane] = id;
+    // (only rectangles of at most BIN_BIG super-tiles are decoded through the table: width <= BIN_BIG;
+    // q / width == (q * inv) >> 16 for q < 1024)
+    tab.a[lane] = make_uint4((unsigned)sr.x0 | (unsigned)sr.y0 << 16,
+                             c ? ((unsigned)(65536 / sw + 1) | (unsigned)sw << 20) : 0u, (unsigned)off, (unsigned)cam_base);
+    tab.b[lane] = pay;
     for (int q = 0; q < c; ++q) tab.owner[off + q] = (unsigned char)lane;
     __syncthreads();                       // hist zeroed, tables complete
     if (dbg & 4) return;                   // diagnostic: price the load + table build alone
@@ -538,11 +538,13 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     // decode pair number p -> bucket (and, for pass 2, everything the record needs)
     auto bucket_of = [&](int p, int& o, int& sx, int& sy) -> int {
         o = tab.owner[p];
-        const int q = p - tab.off[o];
-        const int row = (q * tab.inv[o]) >> 16;
-        sy = tab.sy0[o] + row;
-        sx = tab.sx0[o] + (q - row * tab.sw[o]);
-        return tab.base[o] + sy * g.stw + sx;
+        const uint4 A = tab.a[o];
+        const int q = p - (int)A.z;
+        const int wdt = (int)(A.y >> 20);
+        const int row = (q * (int)(A.y & 0xfffffu)) >> 16;
+        sy = (int)(A.x >> 16) + row;
+        sx = (int)(A.x & 0xffffu) + (q - row * wdt);
+        return (int)A.w + sy * g.stw + sx;
     };
     // large rectangles: the wave walks them together, 64 super-tiles per step
     auto walk_big = [&](auto&& f) {
@@ -598,8 +600,9 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
         int o, sx, sy;
         const int b = bucket_of(p, o, sx, sy);
         const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
-        const unsigned mask = tile_mask(tab.rx0[o], tab.rx1[o], tab.ry0[o], tab.ry1[o], sx, sy);
-        if (!(dbg & 1)) records[slot] = make_uint2(tab.depth[o], tab.id[o] | (mask << 28));
+        const uint4 B = tab.b[o];
+        const unsigned mask = tile_mask((int)(B.x & 0xffffu), (int)(B.x >> 16), (int)(B.y & 0xffffu), (int)(B.y >> 16), sx, sy);
+        if (!(dbg & 1)) records[slot] = make_uint2(B.z, B.w | (mask << 28));
     }
     walk_big([&](int b, const Rect& br, int sx, int sy, unsigned bd, unsigned bi) {
         const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
@@ -1408,13 +1411,13 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     const int seg_bound = big ? (int)seg_bound_for(rec_capacity, L.nsb) : 0;
     if (CN > 262144)
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS, 64>), dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
-                           dim3(FLAT_THREADS), (size_t)L.nsb * 8 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
+                           dim3(FLAT_THREADS), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
                            L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records,
                            g_sc_debug[0]);
     else {
         constexpr int gpb = FLAT_THREADS_SMALL / 64 * 16;
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>), dim3((unsigned)((CN + gpb - 1) / gpb)),
-                           dim3(FLAT_THREADS_SMALL), (size_t)L.nsb * 8 + (FLAT_THREADS_SMALL / 64) * sizeof(FlatTab), s,
+                           dim3(FLAT_THREADS_SMALL), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS_SMALL / 64) * sizeof(FlatTab), s,
                            sorted, cmeta, L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor,
                            records, g_sc_debug[0]);
     }
