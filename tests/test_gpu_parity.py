@@ -1156,6 +1156,49 @@ def test_render_sharded_two_frames_in_flight_is_identical(ops):
     assert not torch.equal(seq[0], seq[5])
 
 
+def test_two_host_threads_render_on_one_device(ops):
+    """Two host threads, each with its own HIP stream, render different frames of different scenes on one device
+    at the same time (the intersection stage's size read-back is a pinned slot + sequence number per
+    HOST THREAD, its kernel attributes are set once per device under a mutex, and the wait for the counts holds
+    no GIL): every frame equals the one rendered alone."""
+    import threading
+    from street_crafter_amd.dist import to_uint8_frame
+    from street_crafter_amd.pipeline import render_gaussians
+    scenes = [make_scene(50_000, seed=31).to(DEV), make_scene(80_000, seed=32, z_range=(1.0, 40.0)).to(DEV)]
+    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.03 * i, shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(8)]
+
+    def frame(w, f):
+        with torch.no_grad():
+            return to_uint8_frame(render_gaussians(scenes[w], cams[f])["rgb"])
+
+    alone = [[frame(w, f).clone() for f in range(8)] for w in range(2)]
+    torch.cuda.synchronize()
+    got = [[None] * 8, [None] * 8]
+    errs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def worker(w):
+        try:
+            with torch.cuda.stream(streams[w]):
+                for rep in range(3):
+                    for f in range(8):
+                        got[w][f] = frame(w, f)
+            streams[w].synchronize()
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for w in range(2):
+        for f in range(8):
+            assert torch.equal(got[w][f], alone[w][f]), (w, f)
+
+
 def test_scene_files_drive_the_renderer(ops, tmp_path):
     """a scene written in the reference's PLY layout (background + a posed actor with Fourier
     colour), read back and composed, renders bit-identically to the in-memory composition; and an actor
