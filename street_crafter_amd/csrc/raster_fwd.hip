@@ -293,9 +293,8 @@ __device__ __forceinline__ void raster_item(
         // ---- blend ---------------------------------------------------------------------------------
         if (dbg & 1) bsz = 0;
         if (bsz > 0) {
-            float4 a = xyoa_s[0], bc = bck_s[0], c = col_s[0];
-            for (int t = 0; t < bsz; ++t) {
-                const float4 an = xyoa_s[t + 1], bcn = bck_s[t + 1], cn = col_s[t + 1];
+            // one blended splat: a = (mx, my, log2 op, A2), bc = (B2, C2, sorted index, -), c = colour
+            auto blend = [&](const float4& a, const float4& bc, const float4& c) {
                 const float dy = a.y - py;
                 const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the lane's pixels
                 const int sidx = __float_as_int(bc.z);
@@ -314,7 +313,7 @@ __device__ __forceinline__ void raster_item(
                     const bool b0 = v0 && !t0, b1 = v1 && !t1;
                     const sc_f2 ae = sc_f2{b0 ? al.x : 0.f, b1 ? al.y : 0.f};   // one select drives vis AND T
                     const sc_f2 vis = ae * T2[p];
-                    T2[p] = __builtin_elementwise_fma(ae, -T2[p], T2[p]);       // == nT when blending, else T
+                    T2[p] = __builtin_elementwise_fma(-ae, T2[p], T2[p]);       // == nT when blending, else T
                     pxp[p] = sc_f2{t0 ? INF : pxp[p].x, t1 ? INF : pxp[p].y};
                     // adding c*0 leaves the sums bit-identical to skipping (sums are never -0)
 #pragma unroll
@@ -331,8 +330,20 @@ __device__ __forceinline__ void raster_item(
                         cur[2 * p + 1] = b1 ? sidx : cur[2 * p + 1];
                     }
                 }
+            };
+            // the next record is read from LDS while the current one blends; two register sets take turns, so
+            // that no record is copied from "next" to "current" (4 v_mov_b64 of ~66 VALU ops per splat)
+            float4 a0 = xyoa_s[0], b0 = bck_s[0], c0 = col_s[0], a1, b1, c1;
+            int t = 0;
+            for (;;) {
+                a1 = xyoa_s[t + 1]; b1 = bck_s[t + 1]; c1 = col_s[t + 1];
+                blend(a0, b0, c0);
                 if (all_done()) { walked += t + 1 - bsz; break; }
-                a = an; bc = bcn; c = cn;
+                if (++t >= bsz) break;
+                a0 = xyoa_s[t + 1]; b0 = bck_s[t + 1]; c0 = col_s[t + 1];
+                blend(a1, b1, c1);
+                if (all_done()) { walked += t + 1 - bsz; break; }
+                if (++t >= bsz) break;
             }
             walked += bsz;
         }
