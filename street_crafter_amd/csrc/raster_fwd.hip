@@ -275,8 +275,11 @@ __device__ __forceinline__ void raster_item(
             if (keep) {
                 const int slot = bsz + __popcll(m & sc_lanemask_lt());
                 const ScSplat sp = sc_prescale(p_xy[j].x, p_xy[j].y, p_a[j], p_b[j], p_c[j], p_op[j]);
-                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.A2 == 0.f ? 1e-37f : sp.A2);
-                bck_s[slot] = make_float4(sp.B2, sp.C2, __int_as_float(batch_start + j * 64 + lane), 0.f);
+                // (mx, lop and A2 are broadcast to pixel PAIRS: they sit in even slots, the low half of a register
+                // pair, which is what v_pk_* can broadcast without a move)
+                xyoa_s[slot] = make_float4(sp.mx, sp.my, sp.lop, sp.B2);
+                bck_s[slot] = make_float4(sp.A2 == 0.f ? 1e-37f : sp.A2, sp.C2,
+                                          __int_as_float(batch_start + j * 64 + lane), 0.f);
                 col_s[slot] = p_col[j];
             }
             bsz += __popcll(m);
@@ -293,16 +296,16 @@ __device__ __forceinline__ void raster_item(
         // ---- blend ---------------------------------------------------------------------------------
         if (dbg & 1) bsz = 0;
         if (bsz > 0) {
-            // one blended splat: a = (mx, my, log2 op, A2), bc = (B2, C2, sorted index, -), c = colour
+            // one blended splat: a = (mx, my, log2 op, B2), bc = (A2, C2, sorted index, -), c = colour
             auto blend = [&](const float4& a, const float4& bc, const float4& c) {
                 const float dy = a.y - py;
-                const float bdy = sc_row_b(bc.x, dy), qdy = sc_row_q(bc.y, dy);   // shared by the lane's pixels
+                const float bdy = sc_row_b(a.w, dy), qdy = sc_row_q(bc.y, dy);    // shared by the lane's pixels
                 const int sidx = __float_as_int(bc.z);
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     // the pinned arithmetic of raster_common.h, two pixels per instruction
                     const sc_f2 dx = sc_f2{a.x, a.x} - pxp[p];
-                    const sc_f2 tt = __builtin_elementwise_fma(sc_f2{a.w, a.w}, dx, sc_f2{bdy, bdy});
+                    const sc_f2 tt = __builtin_elementwise_fma(sc_f2{bc.x, bc.x}, dx, sc_f2{bdy, bdy});
                     const sc_f2 sg = __builtin_elementwise_fma(tt, dx, sc_f2{qdy, qdy});
                     const sc_f2 e = sc_f2{a.z, a.z} - sg;
                     const sc_f2 al = sc_f2{fminf(SC_ALPHA_MAX, __builtin_amdgcn_exp2f(e.x)),
@@ -310,7 +313,7 @@ __device__ __forceinline__ void raster_item(
                     const bool v0 = sc_valid(sg.x, al.x), v1 = sc_valid(sg.y, al.y);
                     const sc_f2 nT = __builtin_elementwise_fma(-al, T2[p], T2[p]);
                     const bool t0 = v0 && (nT.x <= SC_T_EPS), t1 = v1 && (nT.y <= SC_T_EPS);
-                    const bool b0 = v0 && !t0, b1 = v1 && !t1;
+                    const bool b0 = v0 != t0, b1 = v1 != t1;                    // v && !t (t implies v): one mask xor
                     const sc_f2 ae = sc_f2{b0 ? al.x : 0.f, b1 ? al.y : 0.f};   // one select drives vis AND T
                     const sc_f2 vis = ae * T2[p];
                     T2[p] = __builtin_elementwise_fma(-ae, T2[p], T2[p]);       // == nT when blending, else T
@@ -335,10 +338,11 @@ __device__ __forceinline__ void raster_item(
             // that no record is copied from "next" to "current" (4 v_mov_b64 of ~66 VALU ops per splat)
             float4 a0 = xyoa_s[0], b0 = bck_s[0], c0 = col_s[0], a1, b1, c1;
             int t = 0;
+            // (the whole-tile exit vote is taken after every SECOND splat: a splat blended onto finished pixels
+            // changes nothing -- their x is +inf -- and the vote is 3 VALU + 2 SALU ops and a branch)
             for (;;) {
                 a1 = xyoa_s[t + 1]; b1 = bck_s[t + 1]; c1 = col_s[t + 1];
                 blend(a0, b0, c0);
-                if (all_done()) { walked += t + 1 - bsz; break; }
                 if (++t >= bsz) break;
                 a0 = xyoa_s[t + 1]; b0 = bck_s[t + 1]; c0 = col_s[t + 1];
                 blend(a1, b1, c1);
