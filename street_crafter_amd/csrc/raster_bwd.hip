@@ -353,8 +353,8 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
         }
         __syncthreads();
         // ---- replay -----------------------------------------------------------------------------------
-        for (int t = 0; t < bsz; ++t) {
-            const float4 a = xyoa_s[t], bc = bck_s[t], c = col_s[t];
+        // (the next record is read from LDS while the current one is replayed; two register sets take turns)
+        auto replay = [&](const float4& a, const float4& bc, const float4& c) {
             const float cl[4] = {c.x, c.y, c.z, c.w};
             const int sidx = __float_as_int(bc.z);
             const float dy = a.y - py;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
                 }
                 T2[p] = sc_f2{v0 ? Tn.x : T2[p].x, v1 ? Tn.y : T2[p].y};
             }
-            if (!__any(any_valid)) continue;
+            if (!__any(any_valid)) return;
             const float sv = Sv.x + Sv.y, sx = Sx.x + Sx.y, sxx = Sxx.x + Sxx.y;
             float s[16];
 #pragma unroll
@@ -427,6 +427,17 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
             s[11] = -__builtin_amdgcn_exp2f(-a.z) * sv;   // d alpha / d op = alpha_raw / op, i.e. -v_sigma / op
             const float total = wave_transpose_sum16(s, lane);
             if (out_base) atomicAdd(out_base + (int64_t)__float_as_int(bc.w) * out_stride, total);
+        };
+        if (bsz > 0) {
+            float4 a0 = xyoa_s[0], b0 = bck_s[0], c0 = col_s[0], a1, b1, c1;
+            for (int t = 0;;) {
+                a1 = xyoa_s[t + 1]; b1 = bck_s[t + 1]; c1 = col_s[t + 1];
+                replay(a0, b0, c0);
+                if (++t >= bsz) break;
+                a0 = xyoa_s[t + 1]; b0 = bck_s[t + 1]; c0 = col_s[t + 1];
+                replay(a1, b1, c1);
+                if (++t >= bsz) break;
+            }
         }
     }
 }
