@@ -562,8 +562,8 @@ def run_rank(args):
                        "+ 24 B x P (SURVEY 8d)",
                 "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound.  Tiles terminate after "
                         "~12 % of their lists, so the bytes it really moves are ~0.12 of the algorithmic figure "
-                        "(`traffic`); its floor is VALU issue: ~60 VALU instructions incl. 4 v_exp_f32 per blended "
-                        "splat per tile, ~100 us at S-1M (DESIGN.md section 4)"}
+                        "(`traffic`); its floor is VALU issue: ~58 VALU instructions incl. 4 v_exp_f32 per blended "
+                        "splat per tile, ~94 us at S-1M (DESIGN.md section 4)"}
         return stage, ops, roof, I_m
 
     stage_ms, operators, roofline, I_mean = kernel_report(main_rec, n_streams)
