@@ -1035,6 +1035,44 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0][0]).view(np.uint32))
 
 
+@pytest.mark.parametrize("w,h,n", [(3840, 2160, 150_000), (40, 24, 300), (1000, 16, 5_000)])
+def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
+    """The dispatch list on frames the order job treats differently: 32 400 tiles (too many for the smoothed hint's
+    LDS tables: plain per-tile hint), 6 tiles (no room for halves), a single row of tiles.  Three frames each
+    (cold, warm, warm): the list stays a valid cover of the tiles and the pixels do not change."""
+    from street_crafter_amd import _lib, rendering
+    from street_crafter_amd.scenes import make_street_scene
+    cam = make_camera(w, h, 0.6 * w, 0.6 * w)
+    V, K = cam.viewmat[None].to(DEV), cam.K[None].to(DEV)
+    sc = make_street_scene(n, seed=5)[0].to(DEV)
+    kw = dict(near_plane=0.001, far_plane=1000.0, sh_degree=sc.sh_degree, render_mode="RGB+ED", rasterize_mode="antialiased")
+
+    def render():
+        with torch.no_grad():
+            return ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, V, K, w, h, **kw)
+
+    prev = rendering.set_tile_order(False)
+    try:
+        plain = render()
+    finally:
+        rendering.set_tile_order(prev)
+    n_tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    rendering._TILE_WORK.clear()
+    for _ in range(3):
+        rc, ra, meta = render()
+        o = _np(meta["isect_offsets"]._sc_sched[0])
+        assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
+        items = o[o >= 0]
+        assert (o[: items.size] >= 0).all()
+        tiles, kinds = items >> 2, items & 3
+        np.testing.assert_array_equal(np.sort(np.concatenate([tiles[kinds == 0], tiles[kinds == 1]])), np.arange(n_tiles))
+        np.testing.assert_array_equal(np.sort(tiles[kinds == 1]), np.sort(tiles[kinds == 2]))
+        assert (kinds == 1).sum() <= n_tiles // 8
+        np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0]).view(np.uint32))
+        np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[1]).view(np.uint32))
+    assert float(ra.sum()) > 0
+
+
 def test_tile_dispatch_order_in_training(ops):
     """Forward and backward share the order; gradients match the plain dispatch up to fp32 summation order."""
     from street_crafter_amd import rendering
