@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void for_records(const uint2* __restrict__ src, int n
     }
 }
 
-__global__ __launch_bounds__(BS_THREADS) void big_split_kernel(
+__global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
     const uint2* __restrict__ records, uint2* __restrict__ temp, Segment* __restrict__ segs,
     unsigned* __restrict__ n_segs, int seg_bound, const int32_t* __restrict__ soffsets, int n_sbuckets,
     const int64_t* __restrict__ meta, int64_t capacity, int64_t rec_capacity, int64_t super_capacity, int cap,
