@@ -900,6 +900,59 @@ def test_rasterization_fused_matches_composition(ops, render_mode, rasterize_mod
         np.testing.assert_array_equal(a.view(np.uint8), b.view(np.uint8), err_msg=key)
 
 
+@pytest.mark.parametrize("render_mode,rasterize_mode,direct_colors", [
+    ("RGB", "classic", False), ("D", "antialiased", False), ("ED", "classic", False), ("RGB+D", "antialiased", True),
+    ("RGB", "antialiased", True),
+])
+def test_rasterization_other_modes_vs_oracle(ops, render_mode, rasterize_mode, direct_colors):
+    """gsplat's one-call API in the modes the reference's renderer does not use (they take the composition of the
+    operators, not the fused forward): colour only, depth only, expected depth, colours given directly instead of
+    SH coefficients -- against the numpy oracle's operators chained by hand.  Ints bit-exact, pixels 1e-4."""
+    w, h, n = 208, 120, 1500
+    cam = make_camera(w, h, 200.0, 200.0)
+    sc = make_scene(n, sh_degree=2, seed=17, z_range=(1.0, 25.0), scale_range=(0.03, 0.5))
+    aa = rasterize_mode == "antialiased"
+    cols_direct = np.random.default_rng(3).random((n, 3), dtype=np.float32)
+    with torch.no_grad():
+        rc, ra, meta = ops.rasterization(
+            sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), sc.opacities[:, 0].to(DEV),
+            _t(cols_direct).to(DEV) if direct_colors else sc.sh.to(DEV), cam.viewmat[None].to(DEV), cam.K[None].to(DEV),
+            w, h, near_plane=0.01, far_plane=100.0, sh_degree=None if direct_colors else 2, render_mode=render_mode,
+            rasterize_mode=rasterize_mode)
+    assert not meta["fused"] or render_mode in ("RGB+D", "RGB+ED")
+    radii, m2, d, con, comp = O.fully_fused_projection(_np(sc.means), _np(sc.quats), _np(sc.scales), _np(cam.viewmat),
+                                                      _np(cam.K), w, h, near_plane=0.01, far_plane=100.0,
+                                                      calc_compensations=aa)
+    op = _np(sc.opacities[:, 0]) * comp if aa else _np(sc.opacities[:, 0])
+    tw, th = math.ceil(w / 16), math.ceil(h / 16)
+    tpg, ids, fids = O.isect_tiles(m2[None], radii[None], d[None], 16, tw, th, n_cameras=1)
+    offs = O.isect_offset_encode(ids, 1, tw, th)
+    if direct_colors:
+        cols = cols_direct
+    else:
+        V = _np(cam.viewmat).astype(np.float64)
+        center = (-V[:3, :3].T @ V[:3, 3]).astype(np.float32)
+        cols = O.spherical_harmonics(2, _np(sc.means) - center[None], _np(sc.sh), masks=radii > 0)
+        cols = np.maximum(cols + np.float32(0.5), np.float32(0.0))
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = np.concatenate([cols, d[:, None]], axis=-1)
+    elif render_mode in ("D", "ED"):
+        cols = d[:, None]
+    ref_c, ref_a, _, unstable = O.rasterize_to_pixels(m2[None], con[None], cols[None], op[None].astype(np.float32), w, h,
+                                                     16, offs, fids, return_unstable=True)
+    if render_mode in ("ED", "RGB+ED"):
+        ref_c = np.concatenate([ref_c[..., :-1], ref_c[..., -1:] / np.maximum(ref_a, np.float32(1e-10))], axis=-1)
+    np.testing.assert_array_equal(_np(meta["radii"])[0], radii)
+    np.testing.assert_array_equal(_np(meta["flatten_ids"]), fids)
+    np.testing.assert_array_equal(_np(meta["isect_offsets"]), offs)
+    assert rc.shape == ref_c.shape and ra.shape == ref_a.shape
+    stable = ~unstable[0]
+    scale = max(1.0, float(np.abs(ref_c).max()))          # depth channels are in metres
+    assert np.abs(_np(rc)[0][stable] - ref_c[0][stable]).max() <= 1e-4 * scale
+    assert np.abs(_np(ra)[0][stable] - ref_a[0][stable]).max() <= 1e-4
+    assert float(ref_a.sum()) > 0
+
+
 def test_rasterization_fused_equals_reference_caller_sequence(ops):
     """The fused one-call path against the caller's hand-written sequence (pipeline.render_gaussians =
     renderer.py:186-302) on the same camera, camera centre taken from the Camera as the reference does."""
