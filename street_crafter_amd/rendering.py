@@ -247,7 +247,7 @@ def _check_isect_count(n_isects, C, N, tile_width, tile_height):
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
-_TILE_WORK = {}        # (device index, C, tile_width, tile_height) -> int32 [C * tiles]: the list entries every tile
+_TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [C * tiles]: the list entries every tile
                        # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
 _TILE_ORDER = {"on": True}
 _LAZY_ISECT_IDS = {"on": True}
@@ -260,11 +260,17 @@ def set_tile_order(enabled: bool) -> bool:
     return prev
 
 
-def _tile_work(dev, C, tile_width, tile_height) -> Tensor:
-    key = (dev.index, int(C), int(tile_width), int(tile_height))
-    t = _TILE_WORK.get(key)
+def _tile_work(dev, C, N, tile_width, tile_height) -> Tensor:
+    """The rasterizer's per-tile work hint of this frame shape AND Gaussian count: the foreground and the sky pass
+    of a novel-view frame have the same frame shape and must not feed each other's dispatch list.  At most 8
+    buffers are kept (densification changes N every few hundred training steps)."""
+    key = (dev.index, int(C), int(N), int(tile_width), int(tile_height))
+    t = _TILE_WORK.pop(key, None)
     if t is None:
-        t = _TILE_WORK[key] = torch.zeros(int(C) * int(tile_width) * int(tile_height), dtype=torch.int32, device=dev)
+        t = torch.zeros(int(C) * int(tile_width) * int(tile_height), dtype=torch.int32, device=dev)
+        while len(_TILE_WORK) >= 8:
+            _TILE_WORK.pop(next(iter(_TILE_WORK)))
+    _TILE_WORK[key] = t                  # (re-inserted: dicts keep insertion order, the first key is the oldest)
     return t
 
 
@@ -317,7 +323,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     sched = None
     if _TILE_ORDER["on"] and int(tile_size) == 16:
         sched = (torch.empty(lib.sc_tile_order_len(C * tile_width * tile_height), dtype=torch.int32, device=dev),
-                 _tile_work(dev, C, tile_width, tile_height))
+                 _tile_work(dev, C, N, tile_width, tile_height))
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
                                 meta_host.data_ptr(), seq, _p(ws0), ws0.numel(),

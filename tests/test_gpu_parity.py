@@ -1015,7 +1015,8 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     K = torch.stack([c.K for c in cams]).to(DEV)
     from street_crafter_amd.scenes import make_street_scene
     scenes = [make_street_scene(60_000, seed=21)[0].to(DEV),             # a few tiles far above the mean: halves
-              make_scene(20_000, seed=22, z_range=(0.5, 8.0), scale_range=(0.05, 0.4)).to(DEV)]     # even: none
+              make_scene(60_000, seed=22, z_range=(0.5, 8.0), scale_range=(0.02, 0.25)).to(DEV)]    # even: none
+    assert scenes[0].n == scenes[1].n        # same Gaussian count and frame shape: the two scenes share one hint buffer
     kw = dict(near_plane=0.001, far_plane=1000.0, render_mode="RGB+ED", rasterize_mode="antialiased")
 
     def render(sc):
@@ -1035,7 +1036,8 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     split_counts = []
     for which in (0, 0, 1, 0):          # cold, warm, stale hint from scene 0, stale hint from scene 1
         torch.cuda.synchronize()
-        hint = _np(rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), n_cams, w // 16, h // 16)).copy()
+        hint = _np(rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), n_cams, scenes[which].n, w // 16,
+                                        h // 16)).copy()
         rc, ra, meta = render(scenes[which])
         order, work = meta["isect_offsets"]._sc_sched
         torch.cuda.synchronize()
