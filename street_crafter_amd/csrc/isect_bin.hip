@@ -302,12 +302,12 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles] class of every tile
         unsigned short* wk = snap + tpad;    // [tiles] snapshot of tile_work, saturated to 16 bits
         unsigned short* hm = wk + tpad;      // [tiles] its maximum over x - 2 .. x + 2            (both: smooth only)
-        __shared__ int s_lim, s_nsplit;
+        __shared__ int s_lim, s_nsplit, s_tail, s_before;
         const int n_items_max = n_tiles_total + n_tiles_total / 8 + 8;             // == sc_tile_order_len
         const int cap = n_tiles_total / 8;
         const int lane = sc_lane();
         cls[threadIdx.x] = 0;
-        if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; }
+        if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; s_tail = 1024; s_before = 0x7fffffff; }
         // (tile, row, camera) of a thread's k-th tile, i = threadIdx.x + k * BIN_THREADS, without divisions in the loops
         const int tw = g.tile_width, th = g.tile_height;
         const int step_x = BIN_THREADS % tw, step_y = BIN_THREADS / tw;
@@ -392,20 +392,35 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         const unsigned cnt = cls[threadIdx.x];
         unsigned mx;
         const long long run = block_scan_1024((long long)cnt, 0u, &tot, &mx, wave_tot, wave_max);
-        // classes [0, lim) are split: those whose work is at least split_pct % of the heaviest tile's, as far as
-        // the list has room (heavier classes first, whole classes only)
+        // Which tiles are listed as two halves (at most `cap` of them, whole classes only):
+        //  * a SKEWED frame: classes [0, lim), i.e. the tiles whose work is at least split_pct % of the heaviest
+        //    tile's, heaviest classes first -- their walk would be the launch's tail;
+        //  * an even frame: classes [tail_c, 1024), i.e. the LAST tiles of the list -- smaller items at the end of
+        //    the launch even out the ragged last round (S-1M 137.5 -> 132.4 us, whatever the hint is worth).
         const int c_split = 1023 - (int)((((unsigned long long)wmax * (unsigned)split_pct) / 100u) >> shift);
-        const bool mine = split_pct > 0 && wmax >= 32u && skewed && (int)threadIdx.x <= c_split && run + cnt <= cap;
+        const bool on = split_pct > 0 && wmax >= 32u;
+        const bool mine = on && skewed && (int)threadIdx.x <= c_split && run + cnt <= cap;
+        const bool mine_tail = on && !skewed && (long long)n_tiles_total - run <= cap;
         if (mine) { atomicAdd(&s_lim, 1); atomicMax(&s_nsplit, (int)(run + cnt)); }
+        if (mine_tail) { atomicMin(&s_tail, (int)threadIdx.x); atomicMin(&s_before, (int)run); }
         __syncthreads();
-        const int lim = s_lim, n_split = s_nsplit;       // `mine` holds on a prefix of the classes
-        cls[threadIdx.x] = (int)threadIdx.x < lim ? (unsigned)(2 * run) : (unsigned)(run + n_split);
+        const int lim = s_lim;                            // `mine` holds on a prefix of the classes,
+        const int tail_c = s_tail, n_before = min(s_before, n_tiles_total);     // `mine_tail` on a suffix (run is monotone)
+        const int n_split = tail_c < 1024 ? n_tiles_total - n_before : s_nsplit;
+        {
+            const int c = (int)threadIdx.x;
+            unsigned base;
+            if (c < lim) base = (unsigned)(2 * run);
+            else if (c >= tail_c) base = (unsigned)(n_before + 2 * (run - n_before));
+            else base = (unsigned)(run + (tail_c < 1024 ? 0 : n_split));
+            cls[c] = base;
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < n_round; i += BIN_THREADS) {
             const int c = i < n_tiles_total ? (int)snap[i] : -1;
             int hl, len;
             run_of(c, &hl, &len);
-            const unsigned parts = c < lim ? 2u : 1u;
+            const unsigned parts = (c < lim || c >= tail_c) ? 2u : 1u;
             unsigned slot = 0;
             if (hl == lane && c >= 0) slot = atomicAdd(&cls[c], (unsigned)len * parts);
             slot = (unsigned)__shfl((int)slot, hl, 64) + (unsigned)(lane - hl) * parts;
@@ -776,6 +791,7 @@ __device__ __forceinline__ void sort_segment(
         lo = red_lo[w] < lo ? red_lo[w] : lo;
         hi = red_hi[w] > hi ? red_hi[w] : hi;
     }
+    if (dbg & 4) return;                  // diagnostic: price the load + min / max alone (nothing is emitted)
     const double s1 = (double)SS_NC / ((double)(hi - lo) + 1.0);
     // key -> (coarse bin, position inside the bin in [0, 1]); monotone in the key
     auto level1 = [&](unsigned long long K, float& frac) -> int {
@@ -806,6 +822,7 @@ __device__ __forceinline__ void sort_segment(
         coarse[t] = c | (run << 16);
     }
     __syncthreads();
+    if (dbg & 8) return;                  // diagnostic: ... and the coarse counting pass + scan
     auto fine_of = [&](unsigned long long K) -> int {
         float frac;
         const unsigned cs = coarse[level1(K, frac)];
@@ -844,6 +861,7 @@ __device__ __forceinline__ void sort_segment(
         }
     }
     __syncthreads();
+    if (dbg & 32) return;                 // diagnostic: ... and the fine counting pass + scan
     // scatter: after this pass boff[j] is the END of fine bucket j (== start of j + 1)
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {

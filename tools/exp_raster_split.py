@@ -117,6 +117,23 @@ def tail_halves(k):
 
 for k in (300, 600, 1200):
     cands.append((f"tile order, last {k} tiles as halves", tail_halves(k)))
+
+
+def lpt_tail_halves(wk, k, noise):
+    """heaviest first by a NOISY hint (what a moving camera leaves of it), the last k items' tiles as halves"""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    wn = wk.float() * (1.0 + noise * torch.randn(T, device="cuda", generator=g))
+    order = torch.argsort(wn, descending=True, stable=True).to(torch.int32)
+    head, tl = order[: T - k] << 2, order[T - k:]
+    it = torch.cat([head, torch.stack([(tl << 2) | 1, (tl << 2) | 2], 1).reshape(-1)]) if k else order << 2
+    out = torch.full((L,), -1, dtype=torch.int32, device="cuda")
+    out[: it.numel()] = it
+    return out
+
+
+for noise in (0.0, 0.3, 1.0):
+    for k in (0, 1200):
+        cands.append((f"heaviest first, hint noise {noise:.1f}, last {k} as halves", lpt_tail_halves(w, k, noise)))
 res = {n: [] for n, _ in cands}
 for rnd in range(4):                      # round 0 = warm-up (clocks), not shown
     for n, o in cands:
