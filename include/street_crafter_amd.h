@@ -174,8 +174,8 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                      float* render_colors, float* render_alphas,
                      int32_t* last_ids /* nullable: only the backward pass reads it */,
-                     const int32_t* tile_order /* nullable: the DISPATCH LIST, sc_tile_order_len(C*tile_width*tile_height)
-                         items, one per workgroup in launch order (longest-running first: the launch's makespan is one
+                     const int32_t* tile_order /* nullable: the DISPATCH LIST buffer (sc_tile_order_len(C*tile_width*
+                         tile_height) items; the forward reads its leading part), one item per workgroup in launch order (longest-running first: the launch's makespan is one
                          tile's serial walk plus the throughput part).  item = flat tile << 2 | kind: kind 0 = the whole
                          tile, 1 / 2 = its upper / lower 16 x 8 half (a tile whose walk would be the launch's tail is
                          shared by two waves); negative = no work.  Every tile must appear exactly once as kind 0 or
@@ -186,7 +186,9 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                          zero-initialised; stale or half-updated values are fine) */,
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
-/* number of int32 items in a dispatch list for `total_tiles` tiles (every tile + room for the split ones) */
+/* number of int32 items in the dispatch-list buffer for `total_tiles` tiles: the forward's list (total_tiles +
+ * total_tiles / 8 + 8 items: every tile + room for the split ones, padded with -1) followed by the backward's list
+ * (total_tiles items, whole tiles `tile << 2` in the same order: sc_rasterize_bwd reads that part) */
 int sc_tile_order_len(int total_tiles);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
  * with scratch needs no ABI change) */

@@ -240,10 +240,9 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
 
     int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map", order)
     if (order) {
-        // the forward's dispatch list (sc_tile_order_len items): a tile the forward splits appears as kinds 1 and 2
-        // (halves); the backward takes the whole tile at the first and nothing at the second
+        // the backward's part of the dispatch-list buffer: total_tiles items, whole tiles in the forward's order
         const int item = order[blockIdx.x];
-        if (item < 0 || (item & 3) >= 2) return;
+        if (item < 0 || (item & 3) != 0) return;
         tflat = item >> 2;
         if (tflat >= total_tiles) return;
     } else if (map_mode == 0) {
@@ -484,13 +483,14 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
     if (g_sc_raster_bwd_variant == 1 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
-        const int n_blocks = tile_order ? sc_tile_order_len(total_tiles) : total_tiles;
+        const int n_blocks = total_tiles;
+        const int32_t* bwd_order = tile_order ? tile_order + sc_tile_order_fwd_items(total_tiles) : nullptr;
 #define SC_LAUNCH_BWD_WAVE(CD)                                                                                  \
     hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, conics,      \
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \
                        total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,            \
                        v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities,    \
-                       g_sc_raster_map, tile_order)
+                       g_sc_raster_map, bwd_order)
         if (D == 4) SC_LAUNCH_BWD_WAVE(4);
         else SC_LAUNCH_BWD_WAVE(3);
 #undef SC_LAUNCH_BWD_WAVE

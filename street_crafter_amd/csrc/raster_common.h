@@ -105,5 +105,6 @@ __device__ __forceinline__ bool splat_misses_rect(float A, float Bc, float Cc, f
 
 extern int g_sc_raster_bwd_variant;  // sc_set_option "raster_bwd"
 extern "C" int sc_tile_order_len(int total_tiles);     // raster_fwd.hip
+int sc_tile_order_fwd_items(int total_tiles);          // raster_fwd.hip
 extern int g_sc_raster_map;          // sc_set_option "raster_map"
 extern int g_sc_raster_fwd_variant;  // see include/street_crafter_amd.h (sc_set_option "raster_fwd")

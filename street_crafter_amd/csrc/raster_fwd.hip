@@ -436,10 +436,13 @@ int g_sc_raster_map = 1;      // sc_set_option "raster_map": block -> tile map o
 int g_sc_raster_hint_blend = 3;   // sc_set_option "raster_hint_blend": weight (quarters) of the +-2 tile neighbourhood maximum in a tile's hint
 int g_sc_raster_split = 50;   // sc_set_option "raster_split": tiles with >= this % of the heaviest tile's work are halved (0: none)
 
-// Length of a dispatch list for `total_tiles` tiles: every tile once, plus room for the tiles that are split into
-// halves (at most one in eight), padded with -1.
+// Items of the FORWARD's dispatch list for `total_tiles` tiles: every tile once, plus room for the tiles that are split
+// into halves (at most one in eight), padded with -1.
+int sc_tile_order_fwd_items(int total_tiles) { return total_tiles + total_tiles / 8 + 8; }
+
+// Length of the dispatch-list buffer: the forward's list, then the backward's (whole tiles only, same order).
 extern "C" int sc_tile_order_len(int total_tiles) {
-    return total_tiles < 0 ? 0 : total_tiles + total_tiles / 8 + 8;
+    return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles;
 }
 
 extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {
@@ -474,7 +477,7 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
-        const int n_blocks = tile_order ? sc_tile_order_len(total_tiles) : total_tiles;
+        const int n_blocks = tile_order ? sc_tile_order_fwd_items(total_tiles) : total_tiles;
 #define SC_LAUNCH_WAVE(CD, TR)                                                                                      \
     hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d,           \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \

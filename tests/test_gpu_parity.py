@@ -1043,6 +1043,7 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         torch.cuda.synchronize()
         o = _np(order)
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
+        o, o_bwd = o[: n_tiles + n_tiles // 8 + 8], o[n_tiles + n_tiles // 8 + 8:]      # the forward's list, the backward's
         n_items = int((o >= 0).sum())
         assert (o[:n_items] >= 0).all() and (o[n_items:] == -1).all()          # padding at the end only
         tiles, kinds = o[:n_items] >> 2, o[:n_items] & 3
@@ -1052,6 +1053,8 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         first = np.nonzero(kinds == 1)[0]
         assert (kinds[first + 1] == 2).all() and (tiles[first + 1] == halves).all() and (kinds == 3).sum() == 0
         assert (kinds == 2).sum() == halves.size <= n_tiles // 8
+        # the backward's list: the same tiles in the same order, whole
+        np.testing.assert_array_equal(o_bwd, tiles[kinds != 2] << 2)
         np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[which][0]).view(np.uint32))
         np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[which][1]).view(np.uint32))
         # heaviest first, by the class the order job files a tile under: the larger of its own work the previous
@@ -1091,8 +1094,10 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         o = _np(meta["isect_offsets"]._sc_sched[0])
     finally:
         _lib.set_option("raster_split", prev)
-    assert ((o[:n_tiles] & 3) == 0).all() and (o[n_tiles:] == -1).all()
+    n_fwd = n_tiles + n_tiles // 8 + 8
+    assert ((o[:n_tiles] & 3) == 0).all() and (o[n_tiles:n_fwd] == -1).all()
     np.testing.assert_array_equal(np.sort(o[:n_tiles] >> 2), np.arange(n_tiles))
+    np.testing.assert_array_equal(o[n_fwd:], o[:n_tiles])
     np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0][0]).view(np.uint32))
 
 
@@ -1123,6 +1128,8 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
         rc, ra, meta = render()
         o = _np(meta["isect_offsets"]._sc_sched[0])
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
+        o, o_bwd = o[: n_tiles + n_tiles // 8 + 8], o[n_tiles + n_tiles // 8 + 8:]
+        np.testing.assert_array_equal(np.sort(o_bwd), np.arange(n_tiles) << 2)
         items = o[o >= 0]
         assert (o[: items.size] >= 0).all()
         tiles, kinds = items >> 2, items & 3
