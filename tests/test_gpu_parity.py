@@ -743,12 +743,13 @@ def test_train_step_at_config2_full_size(ops):
     assert 0.002 < reached < 0.5, reached
 
 
-@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
-def test_sh_backward_vs_autograd(ops, deg):
+@pytest.mark.parametrize("deg,k_total", [(0, 3), (1, 6), (2, 11), (3, 18), (4, 27),       # rows of odd length: scalar stores
+                                          (0, 4), (1, 4), (1, 16), (2, 16), (3, 16), (4, 28)])  # rows of n x 16 B: float4 rows
+def test_sh_backward_vs_autograd(ops, deg, k_total):
     g = torch.Generator().manual_seed(deg)
     n, K = 2000, (deg + 1) ** 2
     dirs = torch.randn(1, n, 3, generator=g) * 2.0
-    coeffs = torch.randn(1, n, K + 2, 3, generator=g)          # K+2: extra bases must get zero grads
+    coeffs = torch.randn(1, n, k_total, 3, generator=g)         # bases beyond the degree's must get zero grads
     masks = torch.rand(1, n, generator=g) > 0.2
     w = torch.randn(1, n, 3, generator=g)
     dh = dirs.clone().to(DEV).requires_grad_(True)
