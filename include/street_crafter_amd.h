@@ -188,7 +188,8 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      size_t ws_bytes, sc_stream_t stream);
 /* number of int32 items in the dispatch-list buffer for `total_tiles` tiles: the forward's list (total_tiles +
  * total_tiles / 8 + 8 items: every tile + room for the split ones, padded with -1) followed by the backward's list
- * (total_tiles items, whole tiles `tile << 2` in the same order: sc_rasterize_bwd reads that part) */
+ * (total_tiles items, whole tiles `tile << 2` in the same order: sc_rasterize_bwd reads the forward's list by
+ * default -- two waves then add a split tile's gradients -- and this one with sc_set_option raster_bwd_split 0) */
 int sc_tile_order_len(int total_tiles);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
  * with scratch needs no ABI change) */
@@ -267,6 +268,8 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
  *   key "raster_hint_blend": 0..4: a tile's work hint = max(its own, this many quarters of the largest hint within
  *                     2 tiles of it) (default 3; 0 = own value only: exact for a camera that stands still)
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
+ *   key "raster_bwd_split": 1 = the backward follows the forward's dispatch list including its half tiles (default),
+ *                     0 = the whole-tile list behind it
  *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
  *       when non-zero; 0 in production)
  * Returns the previous value, or SC_EINVAL for an unknown key. */

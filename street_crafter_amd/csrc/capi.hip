@@ -56,6 +56,12 @@ extern "C" int sc_set_option(const char* key, int value) {
         g_sc_raster_bwd_variant = value;
         return prev;
     }
+    if (strcmp(key, "raster_bwd_split") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_raster_bwd_split;
+        g_sc_raster_bwd_split = value;
+        return prev;
+    }
     if (strcmp(key, "raster_map") == 0) {
         if (value < 0 || value > 1) return SC_EINVAL;
         const int prev = g_sc_raster_map;

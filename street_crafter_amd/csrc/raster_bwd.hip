@@ -10,6 +10,7 @@
 #include "raster_common.h"
 
 int g_sc_raster_bwd_variant = 1;   // 0 = reference-shaped, 1 = one wave per tile (default)
+int g_sc_raster_bwd_split = 1;     // 1 = the backward follows the forward's dispatch list incl. its half tiles, 0 = whole tiles only
 
 namespace {
 
@@ -220,8 +221,11 @@ __device__ __forceinline__ float wave_transpose_sum16(const float (&v)[16], int 
     return z;
 }
 
-template <int CDIM>
-__global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
+// One wave's share of a tile: the whole 16 x 16 tile (NSUB 1, 4 pixels per lane) or its upper / lower 16 x 8 half
+// (NSUB 2, `sub` 0 / 1, 2 pixels per lane: the forward's dispatch list splits the tiles whose walk would be the
+// launch's tail, and the backward's walk is ~2.5x the forward's).  Both halves add into the same gradients.
+template <int CDIM, int NSUB>
+__device__ __forceinline__ void raster_bwd_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
     const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
@@ -230,33 +234,19 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
-    float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode,
-    const int32_t* __restrict__ order) {
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, int tflat, int sub,
+    float4* xyoa_s, float4* bck_s, float4* col_s) {
     constexpr int SB = 2;
     constexpr int B = 64 * SB;
-    __shared__ float4 xyoa_s[B + 1];      // mx, my, log2(op), A2
-    __shared__ float4 bck_s[B + 1];       // B2, C2, sorted index (int bits), flat id (int bits)
-    __shared__ float4 col_s[B + 1];
-
-    int tflat = blockIdx.x;               // block -> tile map: as raster_fwd_wave_kernel ("raster_map", order)
-    if (order) {
-        // the backward's part of the dispatch-list buffer: total_tiles items, whole tiles in the forward's order
-        const int item = order[blockIdx.x];
-        if (item < 0 || (item & 3) != 0) return;
-        tflat = item >> 2;
-        if (tflat >= total_tiles) return;
-    } else if (map_mode == 0) {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     if (tile_masks && !tile_masks[tflat]) return;
     const int tiles_per_cam = tile_width * tile_height;
     const int cam = tflat / tiles_per_cam;
     const int tile_id = tflat - cam * tiles_per_cam;
     const int tyi = tile_id / tile_width, txi = tile_id - tyi * tile_width;
     const int lane = threadIdx.x;
-    const int px0_i = txi * 16 + 4 * (lane & 3), py_i = tyi * 16 + (lane >> 2);
+    constexpr int NP = NSUB == 1 ? 2 : 1;          // pixel PAIRS per lane (4 or 2 pixels)
+    constexpr int PPL = 2 * NP, LPR = 16 / PPL, ROWS = 16 / NSUB;     // lanes per row, rows this wave covers
+    const int px0_i = txi * 16 + PPL * (lane % LPR), py_i = tyi * 16 + sub * ROWS + lane / LPR;
     const float py = (float)py_i + 0.5f;
     int range_start, range_end;
     sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
@@ -264,12 +254,12 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
 
     // per-pixel state in pairs (pixels 2p, 2p+1): x centre, running transmittance, T_final (v_alpha - bg.v_c),
     // colour sums behind the current splat, upstream colour gradients
-    sc_f2 pxp[2], T2[2], wfin[2], buf2[2][CDIM], vrc[2][CDIM];
-    int bin_final[4];
-    bool ins[4];
+    sc_f2 pxp[NP], T2[NP], wfin[NP], buf2[NP][CDIM], vrc[NP][CDIM];
+    int bin_final[PPL];
+    bool ins[PPL];
     int tile_last = -1;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < PPL; ++k) {
         const int p = k >> 1, h = k & 1;
         ins[k] = (px0_i + k < width) && (py_i < height);
         const int64_t pix = ((int64_t)cam * height + py_i) * width + px0_i + k;
@@ -295,9 +285,9 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     if (tile_last < range_start) return;
 
     const float rx0 = (float)(txi * 16) + 0.5f;
-    const float ry0 = (float)(tyi * 16) + 0.5f;
+    const float ry0 = (float)(tyi * 16 + sub * ROWS) + 0.5f;
     const float rx1 = (float)min(txi * 16 + 15, width - 1) + 0.5f;
-    const float ry1 = (float)min(tyi * 16 + 15, height - 1) + 0.5f;
+    const float ry1 = (float)min(tyi * 16 + sub * ROWS + ROWS - 1, height - 1) + 0.5f;
     constexpr float LN2 = 0.6931471805599453f;
 
     // lane 4 i owns reduced sum i (wave_transpose_sum16): 0..3 colour channels, 4..6 conic, 7..8 mean,
@@ -371,7 +361,7 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
             const float bdy_ln2 = LN2 * bc.x * dy, a2_ln2 = LN2 * 2.0f * a.w;       // d sigma / d mean_x pieces
             const float b2_ln2 = LN2 * bc.x, c2dy_ln2 = LN2 * 2.0f * bc.y * dy;     // d sigma / d mean_y pieces
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 const sc_f2 dx = sc_f2{a.x, a.x} - pxp[p];
                 const sc_f2 sg = __builtin_elementwise_fma(
                     __builtin_elementwise_fma(sc_f2{a.w, a.w}, dx, sc_f2{bdy, bdy}), dx, sc_f2{qdy, qdy});
@@ -441,6 +431,53 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     }
 }
 
+template <int CDIM>
+__global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
+    const float* __restrict__ means2d, const float* __restrict__ conics,
+    const float* __restrict__ colors, const float* __restrict__ opacities,
+    const float* __restrict__ backgrounds, const uint8_t* __restrict__ tile_masks, int N,
+    int width, int height, int tile_width, int tile_height, int total_tiles,
+    const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
+    const float* __restrict__ render_alphas, const int32_t* __restrict__ last_ids,
+    const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
+    float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
+    float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode,
+    const int32_t* __restrict__ order) {
+    constexpr int B = 128;
+    __shared__ float4 xyoa_s[B + 1];      // mx, my, log2(op), A2
+    __shared__ float4 bck_s[B + 1];       // B2, C2, sorted index (int bits), flat id (int bits)
+    __shared__ float4 col_s[B + 1];
+
+    int tflat = blockIdx.x, kind = 0;     // block -> tile map: as raster_fwd_wave_kernel ("raster_map", order)
+    if (order) {
+        // an item of a dispatch list (include/street_crafter_amd.h): tile << 2 | kind, kind 0 = the whole tile,
+        // 1 / 2 = its upper / lower half, negative = no work.  Which of the buffer's two lists the kernel is
+        // given (the forward's, with halves, or the whole-tile one behind it) is the host's choice.
+        const int item = order[blockIdx.x];
+        if (item < 0) return;
+        tflat = item >> 2;
+        kind = item & 3;
+        if (tflat >= total_tiles || kind == 3) return;
+    } else {
+        if (tflat >= total_tiles) return;
+        if (map_mode == 0) {
+            const int nwg = gridDim.x, bid = blockIdx.x;
+            const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+            tflat = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+    }
+    if (kind == 0)
+        raster_bwd_item<CDIM, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                                 tile_height, total_tiles, isect_offsets, flatten_ids, n_isects, render_alphas, last_ids,
+                                 v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors,
+                                 v_opacities, tflat, 0, xyoa_s, bck_s, col_s);
+    else
+        raster_bwd_item<CDIM, 2>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height, tile_width,
+                                 tile_height, total_tiles, isect_offsets, flatten_ids, n_isects, render_alphas, last_ids,
+                                 v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors,
+                                 v_opacities, tflat, kind - 1, xyoa_s, bck_s, col_s);
+}
+
 // unit-test hook for wave_transpose_sum16: in [n_waves][16][64], out [n_waves][64]
 __global__ __launch_bounds__(64) void test_wave_transpose_kernel(const float* __restrict__ in, float* __restrict__ out) {
     float v[16];
@@ -483,8 +520,11 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
     if (g_sc_raster_bwd_variant == 1 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
-        const int n_blocks = total_tiles;
-        const int32_t* bwd_order = tile_order ? tile_order + sc_tile_order_fwd_items(total_tiles) : nullptr;
+        // with a dispatch-list buffer: its forward list (halves included: the backward's long walks are cut like the
+        // forward's) or the whole-tile list behind it (sc_set_option "raster_bwd_split" 0)
+        const bool halves = tile_order && g_sc_raster_bwd_split;
+        const int n_blocks = halves ? sc_tile_order_fwd_items(total_tiles) : total_tiles;
+        const int32_t* bwd_order = !tile_order ? nullptr : (halves ? tile_order : tile_order + sc_tile_order_fwd_items(total_tiles));
 #define SC_LAUNCH_BWD_WAVE(CD)                                                                                  \
     hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, conics,      \
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \

@@ -104,6 +104,7 @@ __device__ __forceinline__ bool splat_misses_rect(float A, float Bc, float Cc, f
 }
 
 extern int g_sc_raster_bwd_variant;  // sc_set_option "raster_bwd"
+extern int g_sc_raster_bwd_split;    // sc_set_option "raster_bwd_split"
 extern "C" int sc_tile_order_len(int total_tiles);     // raster_fwd.hip
 int sc_tile_order_fwd_items(int total_tiles);          // raster_fwd.hip
 extern int g_sc_raster_map;          // sc_set_option "raster_map"

@@ -1142,27 +1142,39 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
     assert float(ra.sum()) > 0
 
 
-def test_tile_dispatch_order_in_training(ops):
-    """Forward and backward share the order; gradients match the plain dispatch up to fp32 summation order."""
-    from street_crafter_amd import rendering
+@pytest.mark.parametrize("shape", ["even", "street"])
+@pytest.mark.parametrize("bwd_split", [1, 0])
+def test_tile_dispatch_order_in_training(ops, shape, bwd_split):
+    """Forward and backward share the dispatch list -- the backward with the forward's half tiles (two waves add into
+    the same gradients) or, `raster_bwd_split` 0, whole tiles in the same order; gradients match the plain dispatch
+    up to fp32 summation order.  "even": the halves are the last tiles of the list; "street": the heaviest."""
+    from street_crafter_amd import _lib, rendering
     from street_crafter_amd.pipeline import render_gaussians
+    from street_crafter_amd.scenes import make_street_scene
     w, h = 400, 272
     cam = make_camera(w, h, 2050.0 * w / 1920.0, 2050.0 * w / 1920.0).to(DEV)
     target = torch.rand(3, h, w, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
-    grads, images = [], []
-    for on in (False, True, True):
-        sc = make_scene(40_000, seed=8).to(DEV)
-        params = (sc.means, sc.quats, sc.scales, sc.opacities, sc.sh)
-        for t in params:
-            t.requires_grad_(True)
-        prev = rendering.set_tile_order(on)
-        try:
-            out = render_gaussians(sc, cam, mode="train")
-            ((out["rgb"] - target).abs().mean() + 0.05 * out["acc"].mean() + 0.01 * out["depth"].mean()).backward()
-        finally:
-            rendering.set_tile_order(prev)
-        images.append(_np(out["rgb"].detach()))
-        grads.append([_np(t.grad) for t in params] + [_np(out["viewspace_points"].absgrad)])
+    grads, images, n_halves = [], [], []
+    prev_split = _lib.set_option("raster_bwd_split", bwd_split)
+    try:
+        for on in (False, True, True):
+            sc = (make_scene(40_000, seed=8) if shape == "even" else make_street_scene(40_000, seed=8)[0]).to(DEV)
+            params = (sc.means, sc.quats, sc.scales, sc.opacities, sc.sh)
+            for t in params:
+                t.requires_grad_(True)
+            prev = rendering.set_tile_order(on)
+            try:
+                out = render_gaussians(sc, cam, mode="train", return_intermediates=True)
+                ((out["rgb"] - target).abs().mean() + 0.05 * out["acc"].mean() + 0.01 * out["depth"].mean()).backward()
+            finally:
+                rendering.set_tile_order(prev)
+            sched = getattr(out["_isect_offsets"], "_sc_sched", None)
+            n_halves.append(0 if sched is None else int(((_np(sched[0])[: 425 + 425 // 8 + 8] & 3) == 1).sum()))
+            images.append(_np(out["rgb"].detach()))
+            grads.append([_np(t.grad) for t in params] + [_np(out["viewspace_points"].absgrad)])
+    finally:
+        _lib.set_option("raster_bwd_split", prev_split)
+    assert n_halves[0] == 0 and n_halves[2] > 0            # 25 x 17 = 425 tiles; the warm list has halves
     np.testing.assert_array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
     np.testing.assert_array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
     for k in (1, 2):

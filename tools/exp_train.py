@@ -20,7 +20,11 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 1600     # the reference trains a
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1066
 STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = "cuda"
-scene = make_scene(N).to(dev)
+if os.environ.get("SC_SCENE") == "street":
+    from street_crafter_amd.scenes import make_street_scene
+    scene = make_street_scene(N)[0].to(dev)
+else:
+    scene = make_scene(N).to(dev)
 cam = make_camera(W, H, 2050.0 * W / 1920.0, 2050.0 * W / 1920.0).to(dev)
 for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.sh):
     t.requires_grad_(True)
@@ -46,6 +50,8 @@ if os.environ.get("SC_RASTER_BWD"):
 if os.environ.get("SC_TILE_ORDER"):
     from street_crafter_amd import rendering
     rendering.set_tile_order(bool(int(os.environ["SC_TILE_ORDER"])))
+if os.environ.get("SC_BWD_SPLIT"):
+    _lib.set_option("raster_bwd_split", int(os.environ["SC_BWD_SPLIT"]))
 if os.environ.get("SC_RASTER_SPLIT"):
     _lib.set_option("raster_split", int(os.environ["SC_RASTER_SPLIT"]))
 for _ in range(3):
