@@ -368,8 +368,9 @@ __device__ __forceinline__ void raster_bwd_item(
                 const sc_f2 e = sc_f2{a.z, a.z} - sg;
                 const sc_f2 araw = sc_f2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};   // op exp(-sigma)
                 const sc_f2 al = sc_f2{fminf(SC_ALPHA_MAX, araw.x), fminf(SC_ALPHA_MAX, araw.y)};
-                const bool v0 = ins[2 * p] && (sidx <= bin_final[2 * p]) && sc_valid(sg.x, al.x);
-                const bool v1 = ins[2 * p + 1] && (sidx <= bin_final[2 * p + 1]) && sc_valid(sg.y, al.y);
+                // (a pixel outside the image has bin_final = -1 < every sorted index: no separate `inside` test)
+                const bool v0 = (sidx <= bin_final[2 * p]) && sc_valid(sg.x, al.x);
+                const bool v1 = (sidx <= bin_final[2 * p + 1]) && sc_valid(sg.y, al.y);
                 any_valid = any_valid || v0 || v1;
                 const sc_f2 om = sc_f2{1.0f, 1.0f} - al;                              // >= 1e-3
                 const sc_f2 ra = sc_f2{__builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y)};
@@ -393,10 +394,14 @@ __device__ __forceinline__ void raster_bwd_item(
                 Sx += vd;
                 Sxx = __builtin_elementwise_fma(vd, dx, Sxx);
                 if (v_means2d_abs) {                                                  // uniform
-                    const sc_f2 gx = __builtin_elementwise_fma(sc_f2{a2_ln2, a2_ln2}, vd, sc_f2{bdy_ln2, bdy_ln2} * vs);
-                    const sc_f2 gy = __builtin_elementwise_fma(sc_f2{b2_ln2, b2_ln2}, vd, sc_f2{c2dy_ln2, c2dy_ln2} * vs);
-                    s_xa += fabsf(gx.x) + fabsf(gx.y);
-                    s_ya += fabsf(gy.x) + fabsf(gy.y);
+                    // |d L / d mean| of a pixel = |v_sigma| |d sigma / d mean|: the second factor needs no v_sigma,
+                    // and the absolute values are source modifiers of the accumulating fma (no separate abs / add)
+                    const sc_f2 gxf = __builtin_elementwise_fma(sc_f2{a2_ln2, a2_ln2}, dx, sc_f2{bdy_ln2, bdy_ln2});
+                    const sc_f2 gyf = __builtin_elementwise_fma(sc_f2{b2_ln2, b2_ln2}, dx, sc_f2{c2dy_ln2, c2dy_ln2});
+                    s_xa = __fmaf_rn(fabsf(vs.x), fabsf(gxf.x), s_xa);
+                    s_xa = __fmaf_rn(fabsf(vs.y), fabsf(gxf.y), s_xa);
+                    s_ya = __fmaf_rn(fabsf(vs.x), fabsf(gyf.x), s_ya);
+                    s_ya = __fmaf_rn(fabsf(vs.y), fabsf(gyf.y), s_ya);
                 }
                 T2[p] = sc_f2{v0 ? Tn.x : T2[p].x, v1 ? Tn.y : T2[p].y};
             }
