@@ -82,6 +82,38 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_isect_workspace_bytes(1_000_000) >= (1_000_000 // 256) * 8
 
 
+def test_host_side_waits_and_list_sizes(lib):
+    """The two host-only entry points: the GIL-free wait for the intersection counts' sequence number (here on plain
+    host memory: value already there, value never arrives -> timeout, a second thread delivers it) and the size of
+    the dispatch-list buffer (forward list incl. room for half tiles + the whole-tile list)."""
+    import ctypes
+    import threading
+    import time
+    word = (ctypes.c_int64 * 1)(7)
+    addr = ctypes.addressof(word)
+    assert lib.sc_wait_i64(addr, 7, 0) == 0
+    t0 = time.perf_counter()
+    assert lib.sc_wait_i64(addr, 8, 20_000) == 1                    # 20 ms timeout
+    assert 0.015 < time.perf_counter() - t0 < 2.0
+    assert lib.sc_wait_i64(None, 0, 0) == -1
+
+    def deliver():
+        time.sleep(0.05)
+        word[0] = 9
+
+    th = threading.Thread(target=deliver)
+    th.start()
+    assert lib.sc_wait_i64(addr, 9, 5_000_000) == 0                 # the waiting call holds no GIL: the thread runs
+    th.join()
+    for tiles in (0, 1, 6, 425, 9600, 36864):
+        assert lib.sc_tile_order_len(tiles) == (tiles + tiles // 8 + 8) + tiles
+    assert lib.sc_tile_order_len(-3) == 0
+    for key in (b"raster_split", b"raster_hint_blend", b"raster_bwd_split", b"raster_map"):
+        prev = lib.sc_set_option(key, 0)
+        assert prev >= 0 and lib.sc_set_option(key, prev) == 0
+    assert lib.sc_set_option(b"raster_split", 101) == -1 and lib.sc_set_option(b"raster_hint_blend", 5) == -1
+
+
 def test_operators_refuse_cpu_tensors(lib):
     from gsplat.rendering import (fully_fused_projection, isect_offset_encode, isect_tiles,
                                   rasterize_to_pixels, spherical_harmonics, rasterization)  # noqa: F401
