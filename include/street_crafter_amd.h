@@ -187,9 +187,10 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                      void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
                      size_t ws_bytes, sc_stream_t stream);
 /* number of int32 items in the dispatch-list buffer for `total_tiles` tiles: the forward's list (total_tiles +
- * total_tiles / 8 + 8 items: every tile + room for the split ones, padded with -1) followed by the backward's list
- * (total_tiles items, whole tiles `tile << 2` in the same order: sc_rasterize_bwd reads the forward's list by
- * default -- two waves then add a split tile's gradients -- and this one with sc_set_option raster_bwd_split 0) */
+ * total_tiles / 8 + 8 items: every tile + room for the split ones, padded with -1), then a whole-tile list in the
+ * same order (total_tiles items `tile << 2`) and one word that says whether that second list was built: it is only
+ * under sc_set_option raster_bwd_split 0 (set BEFORE the frame's sc_isect_bin_count), for a backward that takes
+ * whole tiles; by default sc_rasterize_bwd follows the forward's list, half tiles included. */
 int sc_tile_order_len(int total_tiles);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
  * with scratch needs no ABI change) */

@@ -87,8 +87,44 @@ template <bool LOCAL>
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, Geo g,
     float tile_size, int C, int32_t* __restrict__ tiles_per_gauss, int* __restrict__ dgrid_t,
-    int* __restrict__ dgrid_s, unsigned* __restrict__ chist) {
+    int* __restrict__ dgrid_s, unsigned* __restrict__ chist, int n_count_blocks,
+    const int32_t* __restrict__ tile_work, unsigned* __restrict__ whint, unsigned* __restrict__ wstat, int blend) {
     extern __shared__ int lds_i[];
+    if ((int)blockIdx.x >= n_count_blocks) {
+        // HINT blocks (the launch has CUs to spare: ~120 count workgroups): the rasterizer's per-tile work hint for
+        // the dispatch list, one thread per tile.  tile_work[t] = the work tile t reported the LAST time a frame of
+        // this shape was rasterized; it may be a frame or two old and the camera has moved since, so a tile is filed
+        // under the larger of its own value and blend/4 (default 3/4) of the largest value within 2 tiles of it
+        // (own value: exact for a camera that stands still; neighbourhood: a heavy region that has moved on).
+        // tile_work may be written by another stream's rasterizer right now: any values give a valid list, and the
+        // order job (center_scatter_kernel, block 2) reads each hint once.  Also: the maximum and the sum of the raw
+        // values.  (This was part of the order job, ONE workgroup that had become the last of its launch to
+        // finish: ~10 us of its 21 were these sweeps, instruction-bound on a single CU.)
+        const int T = g.T, tw = g.tile_width, th = g.tile_height, n = C * T;
+        const int i = ((int)blockIdx.x - n_count_blocks) * BIN_THREADS + (int)threadIdx.x;
+        unsigned own = 0, w = 0;
+        if (i < n) {
+            const int cam = i / T, rem = i - cam * T, ty = rem / tw, tx = rem - ty * tw;
+            own = (unsigned)min(max(tile_work[i], 0), 65535);
+            unsigned m = own;
+            if (blend > 0) {
+                const int32_t* base = tile_work + cam * T;
+                for (int yy = max(ty - 2, 0); yy <= min(ty + 2, th - 1); ++yy)
+                    for (int xx = max(tx - 2, 0); xx <= min(tx + 2, tw - 1); ++xx)
+                        m = max(m, (unsigned)min(max(base[yy * tw + xx], 0), 65535));
+            }
+            w = max(own, (m * (unsigned)blend) >> 2);
+            whint[i] = w;
+        }
+        unsigned mx = own, sm = own;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+            sm += (unsigned)__shfl_xor((int)sm, o, 64);
+        }
+        if (sc_lane() == 0 && mx) { atomicMax(&wstat[0], mx); atomicAdd(&wstat[1], sm); }
+        return;
+    }
     const int nt = C * (g.tile_height + 1) * (g.tile_width + 1);
     const int ns = g.ss ? C * (g.sth + 1) * (g.stw + 1) : 0;
     const int nc = C * g.ST;
@@ -248,9 +284,10 @@ __device__ __forceinline__ void publish_meta(const int64_t* __restrict__ meta_de
     mirror[0] = meta_dev[0]; mirror[1] = meta_dev[1]; mirror[2] = meta_dev[2]; mirror[3] = meta_dev[3];
     __hip_atomic_store(&mirror[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void iota_kernel(int32_t* out, int n) {
+// the plain dispatch list (every tile whole, in tile order; no second list) for a frame without Gaussians
+__global__ void plain_order_kernel(int32_t* out, int n_tiles, int n_total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = i;
+    if (i < n_total) out[i] = i < n_tiles ? i << 2 : (i == n_total - 1 ? 0 : -1);
 }
 __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_t* mirror, int64_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
@@ -266,8 +303,8 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
     uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
     unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq,
-    const int32_t* __restrict__ tile_work, int32_t* __restrict__ tile_order, int n_tiles_total, int smooth,
-    int split_pct) {
+    const unsigned* __restrict__ whint, const unsigned* __restrict__ wstat, int32_t* __restrict__ tile_order,
+    int n_tiles_total, int staged, int split_pct, int want_bwd, int odbg) {
     extern __shared__ unsigned lds[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
@@ -295,64 +332,35 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         // (tools/exp_raster_split.py).  Counting sort over 1024 classes of work, heaviest class first; the order
         // inside a class is whatever the atomics give (tile order and random order time the same).
         if (!tile_order) return;
-        // This ONE workgroup must stay shorter than the centre workgroups beside it (~20 us): 16-bit LDS tables, a
-        // separable 5 x 5 maximum, tile coordinates advanced without divisions, run-aggregated LDS atomics.
+        // This ONE workgroup must stay shorter than the centre workgroups beside it (~20 us): the per-tile hints come
+        // ready-made from the count launch's hint blocks (whint, wstat), LDS atomics are aggregated over runs of
+        // equal classes, the list is put together in LDS and written out coalesced.
         unsigned* cls = lds;                 // [1024]
         const int tpad = (n_tiles_total + 1) & ~1;
         unsigned short* snap = reinterpret_cast<unsigned short*>(lds + 1024);     // [tiles] class of every tile
-        unsigned short* wk = snap + tpad;    // [tiles] snapshot of tile_work, saturated to 16 bits
-        unsigned short* hm = wk + tpad;      // [tiles] its maximum over x - 2 .. x + 2            (both: smooth only)
         __shared__ int s_lim, s_nsplit, s_tail, s_before;
         const int n_items_max = n_tiles_total + n_tiles_total / 8 + 8;             // == sc_tile_order_fwd_items
         const int cap = n_tiles_total / 8;
         const int lane = sc_lane();
         cls[threadIdx.x] = 0;
         if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; s_tail = 1024; s_before = 0x7fffffff; }
-        // (tile, row, camera) of a thread's k-th tile, i = threadIdx.x + k * BIN_THREADS, without divisions in the loops
-        const int tw = g.tile_width, th = g.tile_height;
-        const int step_x = BIN_THREADS % tw, step_y = BIN_THREADS / tw;
-        struct Pos { int tx, ty; };
-        auto first_pos = [&]() { const int rem = (int)threadIdx.x % g.T; return Pos{rem % tw, rem / tw}; };
-        auto advance = [&](Pos& p) {
-            p.tx += step_x; p.ty += step_y;
-            if (p.tx >= tw) { p.tx -= tw; ++p.ty; }
-            while (p.ty >= th) p.ty -= th;                     // next camera: rows start again
-        };
-        // tile_work may be written by another stream's rasterizer right now: every value that decides a tile's
-        // place is read ONCE (the sweeps below must agree, or a tile would be listed twice or not at all)
-        unsigned lmax = 0;
-        long long lsum = 0;
-        for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS) {
-            const int w = tile_work ? min(max(tile_work[i], 0), 65535) : 0;
-            if (smooth) wk[i] = (unsigned short)w;
-            else snap[i] = (unsigned short)w;                   // (becomes the class below)
-            lmax = max(lmax, (unsigned)w);
-            lsum += w;
-        }
-        long long tot, wsum;
-        unsigned wmax;
-        block_scan_1024(lsum, lmax, &wsum, &wmax, wave_tot, wave_max);     // (syncs: the snapshot is complete)
+        __shared__ long long s_stamp[10];
+        auto stamp = [&](int k) { if ((odbg & 64) && threadIdx.x == 0) s_stamp[k] = (long long)wall_clock64(); };
+        stamp(0);
+        const unsigned wmax = whint ? wstat[0] : 0u;
+        const long long wsum = whint ? (long long)wstat[1] : 0;
         // halving pays when a few tiles stand far above the rest (street scene: heaviest 7x the mean, -70 us); on
         // an even frame (S-1M: 1.7x) it only adds the halves' second staging (+3 us): ask for 3x the mean
         const bool skewed = (long long)wmax * n_tiles_total >= 3 * wsum;
+        long long tot;
+        stamp(1);
+        if (odbg & 1) return;          // diagnostic (debug1 bit 16): price the start
         int shift = 0;
         while ((wmax >> shift) > 1023u) ++shift;
-        if (smooth) {
-            Pos p = first_pos();
-            for (int i = threadIdx.x; i < n_tiles_total; i += BIN_THREADS, advance(p)) {
-                const unsigned short* row = wk + (i - p.tx);
-                unsigned m = row[p.tx];
-                if (p.tx >= 1) m = max(m, (unsigned)row[p.tx - 1]);
-                if (p.tx >= 2) m = max(m, (unsigned)row[p.tx - 2]);
-                if (p.tx + 1 < tw) m = max(m, (unsigned)row[p.tx + 1]);
-                if (p.tx + 2 < tw) m = max(m, (unsigned)row[p.tx + 2]);
-                hm[i] = (unsigned short)m;
-            }
-            __syncthreads();
-        }
-        // (the smoothed hint has plateaus: neighbouring tiles = neighbouring lanes share a class, and 64 lanes adding
-        // to one LDS counter serialise.  A RUN of equal classes among consecutive lanes is added by its first lane
-        // alone, in both sweeps.)
+        stamp(2);
+        if (odbg & 2) return;
+        // (neighbouring tiles = neighbouring lanes often share a class, and 64 lanes adding to one LDS counter
+        // serialise.  A RUN of equal classes among consecutive lanes is added by its first lane alone, in both sweeps.)
         auto run_of = [&](int c, int* head_lane, int* len) {
             const int prev = __shfl_up(c, 1, 64);
             const unsigned long long heads = __ballot(lane == 0 || c != prev);
@@ -361,34 +369,23 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             *head_lane = 63 - __clzll((long long)(heads & (sc_lanemask_lt() | (1ull << lane))));
         };
         const int n_round = (n_tiles_total + 63) & ~63;                       // whole waves take part in the votes
-        {
-            Pos p = first_pos();
-            for (int i = threadIdx.x; i < n_round; i += BIN_THREADS, advance(p)) {
-                int c = -1;
-                if (i < n_tiles_total) {
-                    unsigned w;
-                    if (smooth) {
-                        // the hint is one or two frames old and the camera has moved since: a tile is filed under
-                        // the larger of its own work and smooth/4 (default 3/4) of the largest work within 2 tiles of it (own value:
-                        // exact for a camera that stands still; neighbourhood: a heavy region that has moved on)
-                        unsigned m = hm[i];
-                        if (p.ty >= 1) m = max(m, (unsigned)hm[i - tw]);
-                        if (p.ty >= 2) m = max(m, (unsigned)hm[i - 2 * tw]);
-                        if (p.ty + 1 < th) m = max(m, (unsigned)hm[i + tw]);
-                        if (p.ty + 2 < th) m = max(m, (unsigned)hm[i + 2 * tw]);
-                        w = max((unsigned)wk[i], (m * (unsigned)smooth) >> 2);
-                    } else {
-                        w = snap[i];
-                    }
-                    c = 1023 - (int)min(1023u, w >> shift);
-                    snap[i] = (unsigned short)c;
-                }
-                int hl, len;
-                run_of(c, &hl, &len);
-                if (hl == lane && c >= 0) atomicAdd(&cls[c], (unsigned)len);
+#pragma unroll 2
+        for (int i = threadIdx.x; i < n_round; i += BIN_THREADS) {
+            int c = -1;
+            if (i < n_tiles_total) {
+                const unsigned w = whint ? min(whint[i], 65535u) : 0u;        // read ONCE: it decides the tile's place
+                c = 1023 - (int)min(1023u, w >> shift);
+                snap[i] = (unsigned short)c;
             }
+            int hl, len;
+            run_of(c, &hl, &len);
+            if (hl == lane && c >= 0) atomicAdd(&cls[c], (unsigned)len);
         }
         __syncthreads();
+        stamp(3);
+        if (odbg & 4) return;          // ... + the class sweep
+        // the forward list is staged in LDS behind the class table (2 B per item) when the launch provides the room
+        unsigned short* stage = staged ? snap + tpad : nullptr;
         const unsigned cnt = cls[threadIdx.x];
         unsigned mx;
         const long long run = block_scan_1024((long long)cnt, 0u, &tot, &mx, wave_tot, wave_max);
@@ -401,8 +398,18 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         const bool on = split_pct > 0 && wmax >= 32u;
         const bool mine = on && skewed && (int)threadIdx.x <= c_split && run + cnt <= cap;
         const bool mine_tail = on && !skewed && (long long)n_tiles_total - run <= cap;
-        if (mine) { atomicAdd(&s_lim, 1); atomicMax(&s_nsplit, (int)(run + cnt)); }
-        if (mine_tail) { atomicMin(&s_tail, (int)threadIdx.x); atomicMin(&s_before, (int)run); }
+        // `mine` holds on a prefix of the classes, `mine_tail` on a suffix (run is monotone): the boundary threads
+        // report, nobody else touches the shared words (a thousand same-address LDS atomics cost microseconds)
+        {
+            const unsigned long long bm = __ballot(mine), bt = __ballot(mine_tail);
+            const bool next_mine = lane < 63 ? ((bm >> (lane + 1)) & 1ull) != 0 : false;      // lane 63: decided below
+            const bool last_here = mine && !next_mine;             // candidate for "last class of the prefix"
+            const bool prev_tail = lane > 0 ? ((bt >> (lane - 1)) & 1ull) != 0 : false;
+            const bool first_here = mine_tail && !prev_tail;       // candidate for "first class of the suffix"
+            // a candidate at a wave boundary may continue in the neighbouring wave: max / min over the candidates decides
+            if (last_here) { atomicMax(&s_lim, (int)threadIdx.x + 1); atomicMax(&s_nsplit, (int)(run + cnt)); }
+            if (first_here) { atomicMin(&s_tail, (int)threadIdx.x); atomicMin(&s_before, (int)run); }
+        }
         __syncthreads();
         const int lim = s_lim;                            // `mine` holds on a prefix of the classes,
         const int tail_c = s_tail, n_before = min(s_before, n_tiles_total);     // `mine_tail` on a suffix (run is monotone)
@@ -416,6 +423,8 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             cls[c] = base;
         }
         __syncthreads();
+        stamp(4);
+        if (odbg & 8) return;          // ... + the class scan and the split decision
         for (int i = threadIdx.x; i < n_round; i += BIN_THREADS) {
             const int c = i < n_tiles_total ? (int)snap[i] : -1;
             int hl, len;
@@ -425,7 +434,12 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             if (hl == lane && c >= 0) slot = atomicAdd(&cls[c], (unsigned)len * parts);
             slot = (unsigned)__shfl((int)slot, hl, 64) + (unsigned)(lane - hl) * parts;
             if (c < 0) continue;
-            if (parts == 2u) {
+            if (stage) {                   // the list is put together in LDS and written out in one coalesced sweep
+                if (slot + parts <= (unsigned)n_items_max) {
+                    stage[slot] = (unsigned short)i;
+                    if (parts == 2u) stage[slot + 1] = (unsigned short)i;
+                }
+            } else if (parts == 2u) {
                 if (slot + 1 < (unsigned)n_items_max) { tile_order[slot] = i << 2 | 1; tile_order[slot + 1] = i << 2 | 2; }
             } else {
                 if (slot < (unsigned)n_items_max) tile_order[slot] = i << 2;
@@ -433,13 +447,41 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             // the BACKWARD's list (whole tiles only, same order) follows the forward's: a kernel that skipped every
             // second item of a run of halves would leave half the XCDs without work there (blocks go round-robin
             // over the XCDs): 284 -> 299 us on the training step's backward
-            unsigned bslot;
-            if (c < lim) bslot = slot >> 1;
-            else if (c >= tail_c) bslot = (unsigned)n_before + ((slot - (unsigned)n_before) >> 1);
-            else bslot = slot - (tail_c < 1024 ? 0u : (unsigned)n_split);
-            if (bslot < (unsigned)n_tiles_total) tile_order[n_items_max + bslot] = i << 2;
+            // (built only when the backward is set to take it, raster_bwd_split 0: this workgroup's scattered
+            // 4-B stores are what it spends most of its time on, and it is the last to finish on small inputs)
+            if (want_bwd) {
+                unsigned bslot;
+                if (c < lim) bslot = slot >> 1;
+                else if (c >= tail_c) bslot = (unsigned)n_before + ((slot - (unsigned)n_before) >> 1);
+                else bslot = slot - (tail_c < 1024 ? 0u : (unsigned)n_split);
+                if (bslot < (unsigned)n_tiles_total) tile_order[n_items_max + bslot] = i << 2;
+            }
         }
-        for (int i = n_tiles_total + n_split + threadIdx.x; i < n_items_max; i += BIN_THREADS) tile_order[i] = -1;
+        if (threadIdx.x == 0) tile_order[n_items_max + n_tiles_total] = want_bwd;       // "the second list is there"
+        const int n_items = n_tiles_total + n_split;
+        stamp(5);
+        if (odbg & 16) return;         // ... + the scatter sweep
+        if (stage) {
+            // (this ONE workgroup's scattered 4-B global stores were what it spent most of its time on -- it had become
+            // the last of the launch to finish: center_scatter 24 -> 29 us on S-1M.)  A tile listed as halves sits in
+            // two neighbouring slots, so the kind of an item follows from its neighbours.
+            __syncthreads();
+            for (int j = threadIdx.x; j < n_items_max; j += BIN_THREADS) {
+                int item = -1;
+                if (j < n_items) {
+                    const int tl = stage[j];
+                    const int kind = (j + 1 < n_items && stage[j + 1] == tl) ? 1 : ((j > 0 && stage[j - 1] == tl) ? 2 : 0);
+                    item = tl << 2 | kind;
+                }
+                tile_order[j] = item;
+            }
+        } else {
+            for (int i = n_items + threadIdx.x; i < n_items_max; i += BIN_THREADS) tile_order[i] = -1;
+        }
+        stamp(6);
+        if ((odbg & 64) && threadIdx.x == 0) {          // diagnostic: stage times in 10-ns ticks at the end of the buffer's forward part
+            for (int k = 0; k < 7; ++k) tile_order[n_items_max - 8 + k] = (int)(s_stamp[k] - s_stamp[0]);
+        }
         return;
     }
     const int cblock = (int)blockIdx.x - 3;
@@ -1225,7 +1267,7 @@ __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
-    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, nseg, scans_done, soffsets, cstart, smeta, cmeta, sorted, total;
+    size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, nseg, scans_done, wstat, soffsets, cstart, smeta, cmeta, whint, sorted, total;
 };
 
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
@@ -1248,10 +1290,12 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.rcursor = take((size_t)L.nsb * 4);
     L.nseg = take(4);
     L.scans_done = take(4);
+    L.wstat = take(16);                                   // maximum and sum of the rasterizer's work hints (zeroed per frame)
     L.soffsets = take((size_t)L.nsb * 4);
     L.cstart = take((size_t)L.nsb * 4);
     L.smeta = take(16);
     L.cmeta = take(16);
+    L.whint = take((size_t)L.ntb * 4);                    // the per-tile hints the order job files the tiles under
     L.sorted = take((size_t)(CN > 0 ? CN : 0) * 16);
     L.total = o;
     return L;
@@ -1318,8 +1362,10 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
             hipLaunchKernelGGL(publish_meta_kernel, dim3(1), dim3(64), 0, s, (const int64_t*)meta_dev, meta_mirror, seq);
             SC_LAUNCH_CHECK();
         }
-        if (tile_order && nb64 > 0) {         // nothing to rasterize, but the order must still be a permutation
-            hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((nb64 + 255) / 256)), dim3(256), 0, s, tile_order, (int)nb64);
+        if (tile_order && nb64 > 0) {         // nothing to rasterize, but the list must still name every tile
+            const int n_total = sc_tile_order_len((int)nb64);
+            hipLaunchKernelGGL(plain_order_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, s, tile_order,
+                               (int)nb64, n_total);
             SC_LAUNCH_CHECK();
         }
         return SC_OK;
@@ -1341,13 +1387,21 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     SC_HIP(hipMemsetAsync(ws, 0, L.soffsets, s));        // difference grids, chist, ccursor, rcursor, rflags
     SC_HIP(bin_attrs_once());
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
+    // the count workgroups, then (with a work hint) one thread per tile that prepares the dispatch list's hints
+    const int n_count_blocks = (int)((CN + CNT_GPB - 1) / CNT_GPB);
+    const bool hints = tile_order && tile_work;
+    const int n_hint_blocks = hints ? (L.ntb + BIN_THREADS - 1) / BIN_THREADS : 0;
+    unsigned* whint = hints ? (unsigned*)(ws + L.whint) : nullptr;
+    unsigned* wstat = (unsigned*)(ws + L.wstat);
     if (local_grids)
-        hipLaunchKernelGGL(bin_count_kernel<true>, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
+        hipLaunchKernelGGL(bin_count_kernel<true>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
                            count_lds_bytes(L), s, means2d, radii, CN,
-                           L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
+                           L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist, n_count_blocks, tile_work,
+                           whint, wstat, g_sc_raster_hint_blend);
     else
-        hipLaunchKernelGGL(bin_count_kernel<false>, dim3((unsigned)((CN + CNT_GPB - 1) / CNT_GPB)), dim3(BIN_THREADS),
-                           0, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist);
+        hipLaunchKernelGGL(bin_count_kernel<false>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
+                           0, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist,
+                           n_count_blocks, tile_work, whint, wstat, g_sc_raster_hint_blend);
     SC_LAUNCH_CHECK();
     // tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3]: two extra
     // blocks of the centre-scatter launch (see the kernel)
@@ -1357,14 +1411,18 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     jobs.j[2] = jobs.j[1];
     unsigned* scans_done = (unsigned*)(ws + L.scans_done);
     size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
-    // the order job: 1024 class counters + a class per tile (+ a snapshot of tile_work for the smoothed hint)
-    const int smooth = (tile_order && tile_work && 4096 + (size_t)L.ntb * 6 + 16 <= 150 * 1024) ? g_sc_raster_hint_blend : 0;
-    const size_t order_lds = 4096 + ((size_t)L.ntb + 1) * (smooth ? 6 : 2) + 16;
+    // the order job: 1024 class counters + a class per tile (2 B) + room to stage the forward list (2 B per item)
+    const size_t n_fwd_items = (size_t)L.ntb + L.ntb / 8 + 8;
+    const size_t order_lds_staged = 4096 + ((size_t)L.ntb + 2) * 2 + n_fwd_items * 2 + 16;
+    const int staged = tile_order && order_lds_staged <= 150 * 1024;
+    const size_t order_lds = staged ? order_lds_staged : 4096 + ((size_t)L.ntb + 2) * 2 + 16;
     if (tile_order && center_lds < order_lds) center_lds = order_lds;
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 3), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
                        depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
-                       meta_mirror, seq, tile_work, tile_order, L.ntb, smooth, g_sc_raster_split);
+                       meta_mirror, seq, (const unsigned*)whint, (const unsigned*)wstat, tile_order, L.ntb, staged,
+                       g_sc_raster_split, g_sc_raster_bwd_split ? 0 : 1,
+                       g_sc_debug[1] >> 16);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
     const float* __restrict__ v_render_colors, const float* __restrict__ v_render_alphas,
     float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities, int map_mode,
-    const int32_t* __restrict__ order) {
+    const int32_t* __restrict__ order, const int32_t* __restrict__ list_ok) {
     constexpr int B = 128;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, log2(op), A2
     __shared__ float4 bck_s[B + 1];       // B2, C2, sorted index (int bits), flat id (int bits)
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(64) void raster_bwd_wave_kernel(
         // an item of a dispatch list (include/street_crafter_amd.h): tile << 2 | kind, kind 0 = the whole tile,
         // 1 / 2 = its upper / lower half, negative = no work.  Which of the buffer's two lists the kernel is
         // given (the forward's, with halves, or the whole-tile one behind it) is the host's choice.
-        const int item = order[blockIdx.x];
+        // (list_ok: for the whole-tile list, the word behind it says whether the intersection stage built it --
+        // it does under raster_bwd_split 0 only; without it the tiles are taken in their own order)
+        const int item = (list_ok == nullptr || *list_ok != 0) ? order[blockIdx.x] : (int)blockIdx.x << 2;
         if (item < 0) return;
         tflat = item >> 2;
         kind = item & 3;
@@ -530,12 +532,13 @@ extern "C" int sc_rasterize_bwd(const float* means2d, const float* conics, const
         const bool halves = tile_order && g_sc_raster_bwd_split;
         const int n_blocks = halves ? sc_tile_order_fwd_items(total_tiles) : total_tiles;
         const int32_t* bwd_order = !tile_order ? nullptr : (halves ? tile_order : tile_order + sc_tile_order_fwd_items(total_tiles));
+        const int32_t* list_ok = (tile_order && !halves) ? tile_order + sc_tile_order_fwd_items(total_tiles) + total_tiles : nullptr;
 #define SC_LAUNCH_BWD_WAVE(CD)                                                                                  \
     hipLaunchKernelGGL(raster_bwd_wave_kernel<CD>, dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, conics,      \
                        colors, opacities, backgrounds, tile_masks, C * N, width, height, tile_width, tile_height,  \
                        total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_alphas, last_ids,            \
                        v_render_colors, v_render_alphas, v_means2d_abs, v_means2d, v_conics, v_colors, v_opacities,    \
-                       g_sc_raster_map, bwd_order)
+                       g_sc_raster_map, bwd_order, list_ok)
         if (D == 4) SC_LAUNCH_BWD_WAVE(4);
         else SC_LAUNCH_BWD_WAVE(3);
 #undef SC_LAUNCH_BWD_WAVE

@@ -440,9 +440,10 @@ int g_sc_raster_split = 50;   // sc_set_option "raster_split": tiles with >= thi
 // into halves (at most one in eight), padded with -1.
 int sc_tile_order_fwd_items(int total_tiles) { return total_tiles + total_tiles / 8 + 8; }
 
-// Length of the dispatch-list buffer: the forward's list, then the backward's (whole tiles only, same order).
+// Length of the dispatch-list buffer: the forward's list, then the whole-tile list (same order; built only under
+// raster_bwd_split 0) and a word that says whether it is there.
 extern "C" int sc_tile_order_len(int total_tiles) {
-    return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles;
+    return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles + 1;     // + "second list present"
 }
 
 extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {

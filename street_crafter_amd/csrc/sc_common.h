@@ -24,6 +24,8 @@
 // that is derived from the skipped producer IN BOUNDS for every consumer -- skip stores, never the
 // computation of counts / offsets other code indexes with, and bound-check at the consumer anyway.
 extern int g_sc_debug[4];
+extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
+extern int g_sc_raster_bwd_split;    // sc_set_option "raster_bwd_split" (raster_bwd.hip)
 extern int g_sc_raster_hint_blend;   // sc_set_option "raster_hint_blend"
 extern int g_sc_raster_split;   // sc_set_option "raster_split" (raster_fwd.hip; read by the order job of isect_bin.hip)
 

@@ -768,11 +768,11 @@ def rasterization(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tenso
                                                           tile_height, packed=False, n_cameras=C)
     isect_offsets = isect_offset_encode(isect_ids, C, tile_width, tile_height)
     if sh_degree is None:
-        cols = colors.reshape(1, N, -1).expand(C, N, -1) if colors.dim() == 2 else colors
+        cols = colors.reshape(1, N, colors.shape[-1]).expand(C, N, -1) if colors.dim() == 2 else colors
     else:
         campos = camera_centers(viewmats) if camera_centers_ is None else camera_centers_.reshape(C, 3)
         dirs = means[None, :, :] - campos[:, None, :]
-        shs = colors.reshape(1, N, -1, 3).expand(C, N, -1, 3)
+        shs = colors.reshape(1, N, colors.shape[-2], 3).expand(C, N, -1, 3)
         cols = spherical_harmonics(sh_degree, dirs, shs, masks=radii > 0)
         cols = torch.clamp_min(cols + 0.5, 0.0)
     if render_mode in ("RGB+D", "RGB+ED"):

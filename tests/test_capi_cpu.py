@@ -106,7 +106,7 @@ def test_host_side_waits_and_list_sizes(lib):
     assert lib.sc_wait_i64(addr, 9, 5_000_000) == 0                 # the waiting call holds no GIL: the thread runs
     th.join()
     for tiles in (0, 1, 6, 425, 9600, 36864):
-        assert lib.sc_tile_order_len(tiles) == (tiles + tiles // 8 + 8) + tiles
+        assert lib.sc_tile_order_len(tiles) == (tiles + tiles // 8 + 8) + tiles + 1
     assert lib.sc_tile_order_len(-3) == 0
     for key in (b"raster_split", b"raster_hint_blend", b"raster_bwd_split", b"raster_map"):
         prev = lib.sc_set_option(key, 0)

@@ -1044,7 +1044,8 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         torch.cuda.synchronize()
         o = _np(order)
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
-        o, o_bwd = o[: n_tiles + n_tiles // 8 + 8], o[n_tiles + n_tiles // 8 + 8:]      # the forward's list, the backward's
+        assert o[-1] == 0        # the whole-tile list behind the forward's is built under raster_bwd_split 0 only
+        o = o[: n_tiles + n_tiles // 8 + 8]                                            # the forward's list
         n_items = int((o >= 0).sum())
         assert (o[:n_items] >= 0).all() and (o[n_items:] == -1).all()          # padding at the end only
         tiles, kinds = o[:n_items] >> 2, o[:n_items] & 3
@@ -1054,8 +1055,6 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         first = np.nonzero(kinds == 1)[0]
         assert (kinds[first + 1] == 2).all() and (tiles[first + 1] == halves).all() and (kinds == 3).sum() == 0
         assert (kinds == 2).sum() == halves.size <= n_tiles // 8
-        # the backward's list: the same tiles in the same order, whole
-        np.testing.assert_array_equal(o_bwd, tiles[kinds != 2] << 2)
         np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[which][0]).view(np.uint32))
         np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[which][1]).view(np.uint32))
         # heaviest first, by the class the order job files a tile under: the larger of its own work the previous
@@ -1089,16 +1088,25 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         assert (wk <= counts + 8 * ((counts + 63) // 64 + 1)).all()
         assert wk.max() > 50
     assert split_counts[0] == 0 and max(split_counts[1:]) > 0          # no hint: nothing is split
+    n_fwd = n_tiles + n_tiles // 8 + 8
+    # raster_bwd_split 0: the whole-tile list for the backward is built too -- the same tiles in the same order
+    prev_b = _lib.set_option("raster_bwd_split", 0)
+    try:
+        rc, ra, meta = render(scenes[0])
+        o = _np(meta["isect_offsets"]._sc_sched[0])
+    finally:
+        _lib.set_option("raster_bwd_split", prev_b)
+    assert o[-1] == 1
+    fwd = o[:n_fwd][o[:n_fwd] >= 0]
+    np.testing.assert_array_equal(o[n_fwd:n_fwd + n_tiles], (fwd[(fwd & 3) != 2] >> 2) << 2)
     prev = _lib.set_option("raster_split", 0)
     try:
         rc, ra, meta = render(scenes[0])
         o = _np(meta["isect_offsets"]._sc_sched[0])
     finally:
         _lib.set_option("raster_split", prev)
-    n_fwd = n_tiles + n_tiles // 8 + 8
     assert ((o[:n_tiles] & 3) == 0).all() and (o[n_tiles:n_fwd] == -1).all()
     np.testing.assert_array_equal(np.sort(o[:n_tiles] >> 2), np.arange(n_tiles))
-    np.testing.assert_array_equal(o[n_fwd:], o[:n_tiles])
     np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0][0]).view(np.uint32))
 
 
@@ -1129,8 +1137,7 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
         rc, ra, meta = render()
         o = _np(meta["isect_offsets"]._sc_sched[0])
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
-        o, o_bwd = o[: n_tiles + n_tiles // 8 + 8], o[n_tiles + n_tiles // 8 + 8:]
-        np.testing.assert_array_equal(np.sort(o_bwd), np.arange(n_tiles) << 2)
+        o = o[: n_tiles + n_tiles // 8 + 8]
         items = o[o >= 0]
         assert (o[: items.size] >= 0).all()
         tiles, kinds = items >> 2, items & 3
@@ -1140,6 +1147,33 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
         np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0]).view(np.uint32))
         np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[1]).view(np.uint32))
     assert float(ra.sum()) > 0
+
+
+def test_frame_without_gaussians_is_rendered_everywhere(ops):
+    """N = 0: the intersection stage's short path still hands the rasterizer a dispatch list that names every tile
+    (in the list's item format), so the whole frame is written: background colour, alpha 0 -- with the list on, and
+    the same with it off."""
+    from street_crafter_amd import rendering
+    w, h = 200, 72
+    cam = make_camera(w, h, 180.0, 180.0)
+    V, K = cam.viewmat[None].to(DEV), cam.K[None].to(DEV)
+    e = lambda *shape: torch.empty(*shape, device=DEV)         # noqa: E731
+    bg = torch.tensor([[0.25, 0.5, 0.75]], device=DEV)
+    outs = []
+    for on in (True, True, False):
+        prev = rendering.set_tile_order(on)
+        try:
+            with torch.no_grad():
+                rc, ra, meta = ops.rasterization(e(0, 3), e(0, 4), e(0, 3), e(0), e(0, 3), V, K, w, h, sh_degree=None,
+                                                 render_mode="RGB", backgrounds=bg)
+        finally:
+            rendering.set_tile_order(prev)
+        torch.cuda.synchronize()
+        assert meta["flatten_ids"].numel() == 0
+        outs.append((_np(rc), _np(ra)))
+    for rc, ra in outs:
+        assert rc.shape == (1, h, w, 3) and (ra == 0).all()
+        np.testing.assert_array_equal(rc, np.broadcast_to(_np(bg)[0], rc.shape))
 
 
 @pytest.mark.parametrize("shape", ["even", "street"])
