@@ -48,6 +48,11 @@ def _hwc_view(x: torch.Tensor):
     return None
 
 
+def _raw_stream(t: torch.Tensor):
+    from .rendering import _stream
+    return _stream(t)
+
+
 def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
                    sky_rgb_chw: Optional[torch.Tensor] = None, rounding: str = "video",
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -77,7 +82,7 @@ def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
             _lib.check(_lib.load().sc_frame_composite_u8(
                 fg[0].data_ptr(), fg[1], None if a is None else a.data_ptr(),
                 None if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1], H * W,
-                ROUNDING[rounding], out.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream),
+                ROUNDING[rounding], out.data_ptr(), _raw_stream(x)),
                 "sc_frame_composite_u8")
             return out
     v = x.float().clamp(0.0, 1.0)

@@ -19,7 +19,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 dev = "cuda"
 W, H = 1920, 1280
 cams = [bench.frame_camera(s, W, H).to(dev) for s in range(frames + 10)]
-sc = make_scene(1_000_000).to(dev)
+sc = make_scene(int(os.environ.get("SC_N", 1_000_000))).to(dev)
 outs = [torch.empty(H, W, 3, dtype=torch.uint8, device=dev) for _ in range(4)]
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
 
