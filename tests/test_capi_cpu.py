@@ -114,6 +114,25 @@ def test_host_side_waits_and_list_sizes(lib):
     assert lib.sc_set_option(b"raster_split", 101) == -1 and lib.sc_set_option(b"raster_hint_blend", 5) == -1
 
 
+def test_work_hint_buffers_are_keyed_and_bounded():
+    """The rasterizer's per-tile work hints: one buffer per (device, cameras, Gaussian count, tile grid) -- the two
+    passes of a novel-view frame must not share one -- and at most 8 of them (densification changes N)."""
+    from street_crafter_amd import rendering
+    rendering._TILE_WORK.clear()
+    dev = torch.device("cpu")
+    a = rendering._tile_work(dev, 1, 1000, 4, 3)
+    b = rendering._tile_work(dev, 1, 31, 4, 3)
+    assert a.shape == b.shape == (12,) and a.data_ptr() != b.data_ptr() and a.dtype == torch.int32
+    assert rendering._tile_work(dev, 1, 1000, 4, 3).data_ptr() == a.data_ptr()
+    assert rendering._tile_work(dev, 2, 1000, 4, 3).shape == (24,)
+    for n in range(2000, 2010):
+        rendering._tile_work(dev, 1, n, 4, 3)
+    assert len(rendering._TILE_WORK) == 8
+    assert rendering._tile_work(dev, 1, 2009, 4, 3) is rendering._TILE_WORK[(None, 1, 2009, 4, 3)]
+    assert (None, 1, 1000, 4, 3) not in rendering._TILE_WORK          # the oldest were dropped
+    rendering._TILE_WORK.clear()
+
+
 def test_operators_refuse_cpu_tensors(lib):
     from gsplat.rendering import (fully_fused_projection, isect_offset_encode, isect_tiles,
                                   rasterize_to_pixels, spherical_harmonics, rasterization)  # noqa: F401
