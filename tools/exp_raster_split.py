@@ -33,7 +33,8 @@ rc = torch.empty(1, H, W, 4, device="cuda"); ra = torch.empty(1, H, W, 1, device
 st = torch.cuda.current_stream().cuda_stream
 work = torch.zeros(T, dtype=torch.int32, device="cuda")
 scratch_work = torch.zeros(T, dtype=torch.int32, device="cuda")
-L = lib.sc_tile_order_len(T)
+L = lib.sc_tile_order_len(T)          # the whole buffer; the forward's list is its first L_FWD items
+L_FWD = T + T // 8 + 8
 
 
 def launch(order=None, wk=scratch_work):
@@ -95,7 +96,7 @@ ref = rc.clone()
 w = work.clone()
 print(which, "work per tile: mean %.0f p50 %.0f p99 %.0f max %d; I=%d" % (w.float().mean(), w.float().median(),
       w.float().quantile(0.99), int(w.max()), fids.numel()))
-cap = L - T
+cap = L_FWD - T
 nlist = torch.diff(torch.cat([off.view(-1), torch.tensor([fids.numel()], dtype=torch.int32, device="cuda")]))
 print("  list length vs work: corr %.3f" % float(torch.corrcoef(torch.stack([nlist.float(), w.float()]))[0, 1]))
 cands = [("no list (tile = block)", None), ("heaviest first, whole tiles", items(w, 2.0, cap)[0]),
@@ -139,5 +140,5 @@ for rnd in range(4):                      # round 0 = warm-up (clocks), not show
     for n, o in cands:
         res[n].append(timeit(o))
 for n, o in cands:
-    launch(o); torch.cuda.synchronize()
+    rc.zero_(); launch(o); torch.cuda.synchronize()
     print(f"  {n:55s} " + " ".join(f"{t:7.1f}" for t in res[n][1:]) + f" us  identical={bool(torch.equal(rc, ref))}")
