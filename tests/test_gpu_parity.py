@@ -1149,6 +1149,53 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
     assert float(ra.sum()) > 0
 
 
+@pytest.mark.parametrize("fill", ["random", "negative", "int_max", "one_hot", "ramp"])
+def test_tile_dispatch_list_survives_any_hint_values(ops, fill):
+    """The work hint is a scheduling hint only: whatever the buffer holds (it may be half written by another stream's
+    rasterizer) the dispatch list must name every tile exactly once -- whole, or as two halves -- and the pixels must
+    not change."""
+    from street_crafter_amd import _lib, rendering
+    w, h, n = 640, 400, 30_000
+    cam = make_camera(w, h, 600.0, 600.0)
+    V, K = cam.viewmat[None].to(DEV), cam.K[None].to(DEV)
+    sc = make_scene(n, seed=41, z_range=(1.0, 40.0)).to(DEV)
+    kw = dict(near_plane=0.001, far_plane=1000.0, sh_degree=sc.sh_degree, render_mode="RGB+ED", rasterize_mode="antialiased")
+
+    def render():
+        with torch.no_grad():
+            return ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, V, K, w, h, **kw)
+
+    prev = rendering.set_tile_order(False)
+    try:
+        plain = render()
+    finally:
+        rendering.set_tile_order(prev)
+    n_tiles = (w // 16) * (h // 16)
+    hint = rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), 1, n, w // 16, h // 16)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    if fill == "random":
+        hint.copy_(torch.randint(-2**31, 2**31 - 1, (n_tiles,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32))
+    elif fill == "negative":
+        hint.fill_(-7)
+    elif fill == "int_max":
+        hint.fill_(2**31 - 1)
+    elif fill == "one_hot":
+        hint.zero_()
+        hint[n_tiles // 2] = 60_000
+    else:
+        hint.copy_(torch.arange(n_tiles, device=DEV, dtype=torch.int32) * 7)
+    rc, ra, meta = render()
+    torch.cuda.synchronize()
+    o = _np(meta["isect_offsets"]._sc_sched[0])[: n_tiles + n_tiles // 8 + 8]
+    items = o[o >= 0]
+    assert (o[: items.size] >= 0).all() and items.size <= n_tiles + n_tiles // 8
+    tiles, kinds = items >> 2, items & 3
+    np.testing.assert_array_equal(np.sort(np.concatenate([tiles[kinds == 0], tiles[kinds == 1]])), np.arange(n_tiles))
+    np.testing.assert_array_equal(np.sort(tiles[kinds == 1]), np.sort(tiles[kinds == 2]))
+    np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0]).view(np.uint32))
+    np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[1]).view(np.uint32))
+
+
 def test_frame_without_gaussians_is_rendered_everywhere(ops):
     """N = 0: the intersection stage's short path still hands the rasterizer a dispatch list that names every tile
     (in the list's item format), so the whole frame is written: background colour, alpha 0 -- with the list on, and
