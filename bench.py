@@ -335,7 +335,9 @@ def run_rank(args):
         t1 = time.perf_counter()
         return t1 - t0, t1 - t_submitted, frames
 
+    spec0 = dict(rendering._BIN_STATS) if not selftest else None
     elapsed_local, drain_s, frames = timed_run(render_into, gatherer, rec=main_rec)
+    spec = None if selftest else {k: rendering._BIN_STATS[k] - spec0[k] for k in spec0}
     elapsed = elapsed_local
     per_rank_fps = [args.steps / elapsed_local]
     if world > 1:
@@ -585,6 +587,11 @@ def run_rank(args):
                                    f"uint8 frames gathered to rank 0 {gatherer.batch} per collective",
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
                        "isect_mode": rendering._ISECT_MODE["mode"], "frames_in_flight": n_streams,
+                       "isect_speculation": dict(spec, what="isect_tiles calls of the headline run incl. warm-up: "
+                                                 "speculative_ok = the scatter + sort launched with sizes predicted "
+                                                 "from the previous frame ran (no host wait in front of them); "
+                                                 "exact_relaunch = the prediction was too small and they were "
+                                                 "launched again with exact sizes; the rest had no prediction yet"),
                        "isect_ids": "lazy (written on first read; nothing on this path reads them)"
                                     if rendering._LAZY_ISECT_IDS["on"] else "written by the sort",
                        "parallelism": f"frames x{world}"},

@@ -289,6 +289,7 @@ def set_lazy_isect_ids(enabled: bool) -> bool:
     return prev
 
 _BIN_LAST_META = {}    # same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
+_BIN_STATS = {"calls": 0, "speculative_ok": 0, "exact_relaunch": 0}   # how often the predicted sizes held (bench.py reports it)
 _PINNED_META = threading.local()   # .slots: device index -> [pinned int64[8] the device publishes meta into, its
                                    # numpy view, seq] of THIS host thread
 
@@ -372,6 +373,11 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     _check_isect_count(n_isects, C, N, tile_width, tile_height)
     # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
     # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
+    _BIN_STATS["calls"] += 1
+    if rc is not None and _bin_launch_ran(pred, n_isects, n_records, max_super):
+        _BIN_STATS["speculative_ok"] += 1
+    elif rc is not None:
+        _BIN_STATS["exact_relaunch"] += 1
     if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):
         if rc is not None:     # a predicted launch was enqueued and (by the device's own check) did nothing:
             # belt and braces, the cursors are re-zeroed before the exact-size launch all the same
