@@ -627,9 +627,11 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
             const unsigned bi = (unsigned)__builtin_amdgcn_readlane((int)id, src);
             // q / bw by multiplication: exact for q < 2^32 / bw (an integer division costs ~40 instructions, and a
             // set of big splats -- a sky -- is walked entirely through this loop)
-            const unsigned binv = 0xffffffffu / (unsigned)bw + 1u;
+            // (bw == 1 -- a big splat clipped to ONE column of super-tiles at the left or right edge of the frame --
+            // has no 32-bit reciprocal: 2^32 / 1 wraps to 0 and every cell landed in row 0, i.e. in the wrong buckets)
+            const unsigned binv = bw > 1 ? 0xffffffffu / (unsigned)bw + 1u : 0u;
             for (int q = lane; q < bcnt; q += 64) {
-                const int row = (int)__umulhi((unsigned)q, binv);
+                const int row = bw > 1 ? (int)__umulhi((unsigned)q, binv) : q;
                 const int sy = by0 + row, sx = bx0 + (q - row * bw);
                 f(bbase + sy * g.stw + sx, br, sx, sy, bd, bi);
             }

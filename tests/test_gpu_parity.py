@@ -231,6 +231,37 @@ def _isect_both_routes(ops, m2, r, d, tw, th, C=1):
     return out
 
 
+@pytest.mark.parametrize("n_small", [0, 300_000])
+@pytest.mark.parametrize("edge", ["left", "right", "top", "bottom"])
+def test_isect_bin_big_splats_clipped_to_one_column_or_row_of_super_tiles(ops, edge, n_small):
+    """Big splats that the frame clips to ONE column (or row) of 2x2 super-tiles, more than 32 super-tiles long: the
+    wave-walked rectangles of the record scatter with width 1 (found by the fuzz tool: the 32-bit reciprocal of a
+    width of 1 wrapped to 0 and every cell went to the first row) -- through the small-input and the large-input
+    scatter kernels, against the reference-shaped route, bit for bit."""
+    tw, th = (44, 140) if edge in ("left", "right") else (140, 44)        # 70 super-tiles along the long side
+    w, h = tw * 16, th * 16
+    g = torch.Generator(device=DEV).manual_seed(7)
+    n_big = 400
+    r_big = 2000
+    along = torch.rand(n_big, device=DEV, generator=g) * (h if edge in ("left", "right") else w)
+    off = {"left": -r_big + 20.0, "right": w + r_big - 20.0, "top": -r_big + 20.0, "bottom": h + r_big - 20.0}[edge]
+    jitter = torch.rand(n_big, device=DEV, generator=g) * 8.0 * (1 if edge in ("left", "top") else -1)
+    if edge in ("left", "right"):
+        m_big = torch.stack([off + jitter, along], dim=-1)
+    else:
+        m_big = torch.stack([along, off + jitter], dim=-1)
+    m_small = torch.rand(n_small, 2, device=DEV, generator=g) * torch.tensor([w, h], device=DEV)
+    m2 = torch.cat([m_big, m_small])[None].contiguous()
+    r = torch.cat([torch.full((n_big,), r_big, dtype=torch.int32, device=DEV),
+                   torch.randint(1, 12, (n_small,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32)])[None].contiguous()
+    d = (torch.rand(1, n_big + n_small, device=DEV, generator=g) * 50.0 + 1.0).contiguous()
+    out = _isect_both_routes(ops, m2, r, d, tw, th)
+    assert out["radix"][2].numel() > n_big * 2 * 100
+    for mode in ("bin", "bin_eager"):
+        for a, b in zip(out["radix"], out[mode]):
+            assert torch.equal(a, b), mode
+
+
 @pytest.mark.parametrize("shape", ["uniform", "cluster_and_outliers", "equal_depths", "heavy_bin", "two_heavy_bins"])
 def test_isect_bin_oversized_super_tiles_are_split_not_abandoned(ops, shape):
     """A super-tile with more records than one workgroup sorts in LDS (3584) used to send the WHOLE frame down

@@ -18,6 +18,7 @@ from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
+ONLY = int(os.environ.get("FUZZ_ONLY", -1))
 for it in range(ROUNDS):
     n = int(rng.choice([1, 7, 500, 20_000, 150_000, 600_000]))
     W = int(rng.integers(17, 4000)); H = int(rng.integers(17, 2300))
@@ -37,6 +38,8 @@ for it in range(ROUNDS):
         sc.means[:, 2] = torch.round(sc.means[:, 2])
     f = 2050.0 * W / 1920.0
     cams = [make_camera(W, H, f, f, yaw=0.05 * i, shift=(0.2 * i, 0.0, 0.0)) for i in range(C)]
+    if ONLY >= 0 and it != ONLY:           # FUZZ_ONLY=k: replay iteration k of this seed alone (all draws are made above)
+        continue
     V = torch.stack([c.viewmat for c in cams]).cuda(); K = torch.stack([c.K for c in cams]).cuda()
     with torch.no_grad():
         radii, m2, d, con, comp = R.fully_fused_projection(sc.means, None, sc.quats, sc.scales, V, K, W, H,
@@ -61,6 +64,25 @@ for it in range(ROUNDS):
             print(f"[{it}] N={n} C={C} {W}x{H} smax={smax} z>={zmin}: more than 2^31 - 1 intersections, refused by both routes", flush=True)
             continue
         ok_isect = all(torch.equal(a, b) for a, b in zip(outs["bin"], outs["radix"]))
+        if not ok_isect:
+            print("    bucketed route meta (n_isects, n_records, largest super-tile):", list(rendering._BIN_LAST_META.values())[-1:])
+            offb = outs["radix"][3].reshape(-1).long()
+            dd = (outs["bin"][2] != outs["radix"][2]).nonzero().reshape(-1)
+            tiles_bad = torch.unique(torch.searchsorted(offb, dd, right=True) - 1)
+            tw_ = (W + 15) // 16
+            print("    tiles with a wrong list:", tiles_bad.numel(), "first (tx,ty):", [(int(t) % tw_, int(t) // tw_) for t in tiles_bad[:12]],
+                  "list lengths:", [int((offb[t + 1] if t + 1 < offb.numel() else outs['radix'][2].numel()) - offb[t]) for t in tiles_bad[:12]])
+            for mode_ in ("bin", "radix"):          # (no indexing with the lists' own ids: they may be garbage)
+                ids_, fids_ = outs[mode_][1], outs[mode_][2]
+                print(f"    {mode_}: isect_ids ascending {bool((ids_[1:] >= ids_[:-1]).all())}, flatten_ids in [{int(fids_.min())}, "
+                      f"{int(fids_.max())}] of {C * n}, sum {int(fids_.long().sum())}")
+            for name, a, b in zip(("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"), outs["bin"], outs["radix"]):
+                if a.shape != b.shape:
+                    print(f"    {name}: shapes {tuple(a.shape)} vs {tuple(b.shape)}")
+                elif not torch.equal(a, b):
+                    d = (a.reshape(-1) != b.reshape(-1)).nonzero().reshape(-1)
+                    print(f"    {name}: {d.numel()} of {a.numel()} differ, first at {int(d[0])}: bin {a.reshape(-1)[d[:4]].tolist()} "
+                          f"radix {b.reshape(-1)[d[:4]].tolist()}, last at {int(d[-1])}")
         op = sc.opacities[None, :, 0] * comp
         cols = torch.rand(C, n, 4, device="cuda")
         imgs = {}
@@ -84,9 +106,34 @@ for it in range(ROUNDS):
                 rendering.set_fused_rasterization(prev)
         ok_fused = torch.equal(fr[0][0].view(torch.int32), fr[1][0].view(torch.int32)) and \
             torch.equal(fr[0][1].view(torch.int32), fr[1][1].view(torch.int32)) and fr[0][2]["fused"] and not fr[1][2]["fused"]
+    # backward: the wave-per-tile kernel (with the dispatch list of the second, warm call: half tiles included) against
+    # the reference-shaped one, through the train-mode render of the first camera
+    ok_bwd = True
+    if n <= 150_000 and W * H <= 1600 * 1100:
+        from street_crafter_amd.pipeline import render_gaussians
+        cam0 = cams[0].to("cuda")
+        target = torch.rand(3, H, W, device="cuda")
+        grads = []
+        for variant in (1, 1, 0):
+            params = [t.detach().clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.sh)]
+            scn = type(sc)(*params, sc.sh_degree)
+            prev = _lib.set_option("raster_bwd", variant)
+            try:
+                out = render_gaussians(scn, cam0, mode="train")
+                ((out["rgb"] - target).abs().mean() + 0.05 * out["acc"].mean() + 0.01 * out["depth"].mean()).backward()
+            finally:
+                _lib.set_option("raster_bwd", prev)
+            grads.append([p.grad.detach().clone() for p in params])
+        for name, a, b in zip(("means", "quats", "scales", "opacities", "sh"), grads[1], grads[2]):
+            den = float(b.abs().max()) + 1e-20
+            err = float((a - b).abs().max()) / den
+            if not bool(torch.isfinite(a).all()) or err > 5e-4:
+                ok_bwd = False
+                print(f"    backward: {name} differs by {err:.3e} of its largest entry ({den:.3e}); finite {bool(torch.isfinite(a).all())}")
     I = outs["bin"][1].numel()
     print(f"[{it}] N={n} C={C} {W}x{H} smax={smax} z>={zmin} deg={deg} I={I}: isect {'ok' if ok_isect else 'MISMATCH'}, "
-          f"raster {'ok' if ok_raster else 'MISMATCH'}, fused {'ok' if ok_fused else 'MISMATCH'}", flush=True)
-    bad += (not ok_isect) + (not ok_raster) + (not ok_fused)
+          f"raster {'ok' if ok_raster else 'MISMATCH'}, fused {'ok' if ok_fused else 'MISMATCH'}, "
+          f"backward {'ok' if ok_bwd else 'MISMATCH'}", flush=True)
+    bad += (not ok_isect) + (not ok_raster) + (not ok_fused) + (not ok_bwd)
 print("FAILED" if bad else "all paths agree")
 sys.exit(1 if bad else 0)
