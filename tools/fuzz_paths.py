@@ -36,8 +36,12 @@ for it in range(ROUNDS):
         n = sc.n
     if rng.random() < 0.3 and n > 10:          # many equal depths: only the id bits of the sort key separate them
         sc.means[:, 2] = torch.round(sc.means[:, 2])
-    f = 2050.0 * W / 1920.0
-    cams = [make_camera(W, H, f, f, yaw=0.05 * i, shift=(0.2 * i, 0.0, 0.0)) for i in range(C)]
+    # focal length and view direction vary too: a long lens turns every splat into a big one, a turned camera puts the
+    # scene's edge -- and with it splats clipped by the frame border -- into view
+    f = 2050.0 * W / 1920.0 * float(rng.choice([0.5, 1.0, 1.0, 3.0]))
+    yaw0 = float(rng.choice([0.0, 0.0, 0.25, -0.4]))
+    lift = float(rng.choice([0.0, 0.0, 1.5]))
+    cams = [make_camera(W, H, f, f, yaw=yaw0 + 0.05 * i, shift=(0.2 * i, lift, 0.0)) for i in range(C)]
     if ONLY >= 0 and it != ONLY:           # FUZZ_ONLY=k: replay iteration k of this seed alone (all draws are made above)
         continue
     V = torch.stack([c.viewmat for c in cams]).cuda(); K = torch.stack([c.K for c in cams]).cuda()
@@ -130,7 +134,8 @@ for it in range(ROUNDS):
         # float-atomic noise of EITHER kernel reaches 5e-4 .. 2e-2 of the largest quaternion gradient for splats metres
         # wide -- two runs of the reference-shaped kernel differ by as much, tools/debug_bwd_fuzz.py)
         for name, a, b in zip(("opacities", "sh", "means2d", "absgrad"), grads[1], grads[2]):
-            den = float(b.abs().max()) + 1e-20
+            # (means2d: pixel contributions of both signs nearly cancel for an isolated splat; its scale is absgrad's)
+            den = float((grads[2][3] if name == "means2d" else b).abs().max()) + 1e-20
             err = float((a - b).abs().max()) / den
             if not bool(torch.isfinite(a).all()) or err > 5e-4:
                 ok_bwd = False
