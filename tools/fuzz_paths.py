@@ -88,12 +88,16 @@ for it in range(ROUNDS):
                     print(f"    {name}: {d.numel()} of {a.numel()} differ, first at {int(d[0])}: bin {a.reshape(-1)[d[:4]].tolist()} "
                           f"radix {b.reshape(-1)[d[:4]].tolist()}, last at {int(d[-1])}")
         op = sc.opacities[None, :, 0] * comp
-        cols = torch.rand(C, n, 4, device="cuda")
+        D = 3 if (it % 3 == 1) else 4                       # the wave kernel exists for 3 and 4 channels
+        cols = torch.rand(C, n, D, device="cuda")
+        bgs = torch.rand(C, D, device="cuda") if it % 2 == 0 else None
+        tmask = (torch.rand(C, th, tw, device="cuda") < 0.7) if it % 4 == 3 else None
         imgs = {}
         for v in (3, 0):
             prev = _lib.set_option("raster_fwd", v)
             try:
-                imgs[v] = R.rasterize_to_pixels(m2, con, cols, op, W, H, 16, outs["bin"][3], outs["bin"][2])
+                imgs[v] = R.rasterize_to_pixels(m2, con, cols, op, W, H, 16, outs["bin"][3], outs["bin"][2],
+                                                backgrounds=bgs, masks=tmask)
             finally:
                 _lib.set_option("raster_fwd", prev)
         ok_raster = all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(imgs[3], imgs[0]))
