@@ -1,0 +1,54 @@
+"""Randomised check of the novel-view frame as the sharded loop produces it (foreground pass + sky pass through the fused
+rasterization(), composite + clamp + uint8 in one kernel) against the oracle: the C restatement renders both passes,
+the numpy oracle composites and quantises.  uint8 frames may differ by one step where the float images differ by
+~1e-6 across a quantisation boundary (and by more on the isolated threshold-flip pixels DESIGN 2 describes).
+Test infrastructure.  Usage: python tools/fuzz_two_pass.py [seed] [rounds]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import gsplat_oracle as O  # noqa: E402
+from oracle import gsplat_oracle_c as OC  # noqa: E402
+from street_crafter_amd.pipeline import render_novel_view_u8  # noqa: E402
+from street_crafter_amd.scenes import make_camera, make_street_scene  # noqa: E402
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+bad = 0
+for it in range(ROUNDS):
+    n = int(rng.choice([2_000, 40_000, 200_000]))
+    W = int(rng.integers(64, 1921)); H = int(rng.integers(64, 1281))
+    deg = int(rng.integers(0, 4))
+    f = 2050.0 * W / 1920.0 * float(rng.choice([0.6, 1.0, 1.8]))
+    yaw = float(rng.choice([0.0, 0.25, -0.3]))
+    rounding = str(rng.choice(["video", "save_image"]))
+    fg, sky = make_street_scene(n, n_sky=max(8, n // int(rng.choice([16, 32, 64]))), sh_degree=deg, seed=int(rng.integers(1 << 30)))
+    cam = make_camera(W, H, f, f, yaw=yaw)
+    with torch.no_grad():
+        for fused in (True, False):
+            got = render_novel_view_u8(fg.to("cuda"), sky.to("cuda"), cam.to("cuda"), rounding=rounding, fused=fused)
+            if fused:
+                got_fused = got.clone()
+    torch.cuda.synchronize()
+    same_paths = bool(torch.equal(got, got_fused))
+
+    def one(s):
+        return OC.render_frame(s.means.numpy(), s.quats.numpy(), s.scales.numpy(), s.opacities.numpy(), s.sh.numpy(),
+                               cam.viewmat.numpy(), cam.K.numpy(), W, H, deg, return_unstable=True)
+    rf, rs = one(fg), one(sky)
+    rgb = O.composite_sky(rf["render_colors"][0, ..., :3], rf["render_alphas"][0], rs["render_colors"][0, ..., :3])
+    ref = O.quantise_u8(rgb, rounding)
+    g = got_fused.cpu().numpy().astype(np.int32)
+    diff = np.abs(g - ref.astype(np.int32)).max(axis=-1)
+    stable = ~(rf["unstable"][0] | rs["unstable"][0])
+    n1 = int(((diff == 1) & stable).sum())
+    n2 = int(((diff > 1) & stable).sum())
+    ok = same_paths and n1 <= max(4, int(2e-4 * diff.size)) and n2 <= max(2, int(1e-4 * diff.size))
+    print(f"[{it}] fg {fg.n} + sky {sky.n}, {W}x{H} deg={deg} f={f:.0f} yaw={yaw} {rounding}: fused == unfused {same_paths}; vs oracle on "
+          f"{stable.mean() * 100:.2f} % stable pixels: {n1} off by one step, {n2} by more: {'ok' if ok else 'FAIL'}", flush=True)
+    bad += not ok
+print("FAILED" if bad else "two-pass uint8 frames agree with the oracle")
