@@ -1,13 +1,13 @@
 """Randomised check of the rasterizer's BACKWARD (both kernels) against the float64 autograd oracle
 (oracle/gsplat_torch.py) on small random scenes: gradients of means2d, conics, colours, opacities and the exact
 absgrad, 2e-3 of the largest entry (the bar of tests/test_gpu_parity.py), pixels the oracle flags threshold-unstable
-left out of the loss.  Test infrastructure: never imported by the product.
-Usage: python tools/fuzz_grad.py [seed] [rounds]"""
+left out of the loss.  Test infrastructure (it uses oracle/): lives under tests/, never imported by the product.
+Usage: python tests/fuzz/fuzz_grad.py [seed] [rounds]"""
 import math
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

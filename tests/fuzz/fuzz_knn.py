@@ -1,11 +1,11 @@
 """Randomised check of simple_knn.distCUDA2 (mean squared distance to the 3 nearest neighbours): bit-exact against
 the oracle (oracle/knn_oracle.py) for clouds up to 20 k points, against scipy's exact k-NN (float64) beyond, over
 degenerate shapes: duplicates, a plane, a line, tight clusters far apart, 1..5 points, huge coordinates.
-Test infrastructure.  Usage: python tools/fuzz_knn.py [seed] [rounds]"""
+Test infrastructure (it uses oracle/): lives under tests/.  Usage: python tests/fuzz/fuzz_knn.py [seed] [rounds]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

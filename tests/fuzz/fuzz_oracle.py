@@ -2,12 +2,12 @@
 restatement (oracle/gsplat_oracle_c.c, pinned bit for bit to the numpy oracle by tests/test_oracle_cpu.py) against
 the HIP path.  Integer outputs and projection / SH floats bit-exact; pixels within 1e-4 on the pixels the oracle does
 not flag threshold-unstable.  (tools/fuzz_paths.py compares the GPU paths with each other; this one compares them
-with the checker.)  Test infrastructure: never imported by the product.
-Usage: python tools/fuzz_oracle.py [seed] [rounds]"""
+with the checker.)  Test infrastructure (it uses oracle/): lives under tests/, never imported by the product.
+Usage: python tests/fuzz/fuzz_oracle.py [seed] [rounds]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -2,11 +2,11 @@
 rasterization(), composite + clamp + uint8 in one kernel) against the oracle: the C restatement renders both passes,
 the numpy oracle composites and quantises.  uint8 frames may differ by one step where the float images differ by
 ~1e-6 across a quantisation boundary (and by more on the isolated threshold-flip pixels DESIGN 2 describes).
-Test infrastructure.  Usage: python tools/fuzz_two_pass.py [seed] [rounds]"""
+Test infrastructure (it uses oracle/): lives under tests/.  Usage: python tests/fuzz/fuzz_two_pass.py [seed] [rounds]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
