@@ -343,13 +343,22 @@ def spherical_harmonics(degree, dirs, coeffs, masks=None):
 # --------------------------------------------------------------------------
 def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_height,
                         tile_size, isect_offsets, flatten_ids, backgrounds=None,
-                        masks=None, return_unstable=False, unstable_rel=2e-5):
+                        masks=None, return_unstable=False, unstable_rel=2e-5, unstable_cond=0.0,
+                        return_cond_bound=False):
     """means2d [C,N,2], conics [C,N,3], colors [C,N,D], opacities [C,N],
     isect_offsets i32[C,th,tw], flatten_ids i32[I].
     Returns render_colors f32[C,H,W,D], render_alphas f32[C,H,W,1], last_ids i32[C,H,W]
     (+ unstable bool[C,H,W] when asked: pixels where some alpha or transmittance sits
     within `unstable_rel` of a hard threshold, so that a 1-ulp change of exp() may
-    legitimately flip the skip / terminate decision)."""
+    legitimately flip the skip / terminate decision).
+    `unstable_cond` > 0 (optional; the fixtures and digests were made with 0) widens each window by the
+    rounding-error bound of the quantity it guards: sigma is a sum of terms of magnitude
+    S = (|A| dx^2 + |C| dy^2) / 2 + |B dx dy|, so another order of the same operations moves it by about
+    unstable_cond * 2^-24 * S (S >> sigma for a big rotated splat), alpha by that relative amount and the
+    transmittance by the accumulated relative errors of its factors.
+    `return_cond_bound` (with return_unstable and unstable_cond > 0) appends f32[C,H,W]: the first-order bound of
+    what the same rounding error does to the blend itself, sum_i vis_i (ea_i + 3 eps + terr_i) + T terr, in units
+    of the colour scale (ea_i: bound of alpha_i's relative error, terr_i: of the transmittance up to splat i)."""
     means2d = _f(means2d)
     conics = _f(conics)
     colors = _f(colors)
@@ -365,6 +374,8 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
     out_a = np.zeros((C, H, W, 1), dtype=np.float32)
     out_l = np.zeros((C, H, W), dtype=np.int32)
     unstable = np.zeros((C, H, W), dtype=bool)
+    want_bound = bool(return_cond_bound and return_unstable and unstable_cond > 0)
+    cond_bound = np.zeros((C, H, W), dtype=np.float32)
     flat_off = offs.reshape(-1)
     m2 = means2d.reshape(-1, 2)
     cn = conics.reshape(-1, 3)
@@ -424,9 +435,28 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
                                     F32(1.0)).astype(np.float32)
                     if return_unstable:
                         considered = kk <= np.minimum(stop, G - 1)[None, :]
-                        ra = np.abs(alpha - ALPHA_MIN) <= F32(unstable_rel) * ALPHA_MIN
-                        rs = np.abs(sigma) <= F32(1e-6)
-                        rt = ok & (np.abs(T_after - T_EPS) <= F32(unstable_rel * 10) * T_EPS)
+                        if unstable_cond > 0:
+                            with np.errstate(all="ignore"):
+                                eps24 = F32(2.0 ** -24)
+                                ce = F32(unstable_cond) * eps24
+                                S = F32(0.5) * (np.abs((ca * dx) * dx) + np.abs((cc * dy) * dy)) + np.abs((cb * dx) * dy)
+                                ea = ce * S          # error bound of sigma == relative error bound of alpha
+                                wa = F32(unstable_rel) + ea
+                                ws = F32(1e-6) + ea
+                                t_terms = np.where(ok, (a_eff * (ea + F32(3.0) * eps24)) / om + eps24, F32(0.0))
+                                wt = F32(unstable_rel) * F32(10.0) + np.cumsum(t_terms, axis=0, dtype=np.float32)
+                                ra = np.abs(alpha - ALPHA_MIN) <= wa * ALPHA_MIN
+                                rs = np.abs(sigma) <= ws
+                                rt = ok & (np.abs(T_after - T_EPS) <= wt * T_EPS)
+                                if want_bound:
+                                    terr = np.cumsum(t_terms, axis=0, dtype=np.float32)
+                                    b_terms = np.where(live, vis * ((ea + F32(3.0) * eps24) + terr), F32(0.0))
+                                    terr_fin = terr[np.minimum(stop, G - 1), np.arange(P)]
+                                    bnd = np.cumsum(b_terms, axis=0, dtype=np.float32)[-1] + Tfin * terr_fin
+                        else:
+                            ra = np.abs(alpha - ALPHA_MIN) <= F32(unstable_rel) * ALPHA_MIN
+                            rs = np.abs(sigma) <= F32(1e-6)
+                            rt = ok & (np.abs(T_after - T_EPS) <= F32(unstable_rel * 10) * T_EPS)
                         unst = ((ra | rs | rt) & considered).any(axis=0)
                     else:
                         unst = np.zeros(P, dtype=bool)
@@ -436,6 +466,10 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
                 out_a[c, y0:y1, x0:x1, 0] = (F32(1.0) - Tfin).reshape(hh, ww)
                 out_l[c, y0:y1, x0:x1] = last.reshape(hh, ww)
                 unstable[c, y0:y1, x0:x1] = unst.reshape(hh, ww)
+                if want_bound and G > 0:
+                    cond_bound[c, y0:y1, x0:x1] = bnd.reshape(hh, ww)
+    if want_bound:
+        return out_c, out_a, out_l, unstable, cond_bound
     if return_unstable:
         return out_c, out_a, out_l, unstable
     return out_c, out_a, out_l
@@ -446,7 +480,7 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
 # --------------------------------------------------------------------------
 def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height,
                  sh_degree, cam_center=None, tile_size=16, near_plane=0.001, far_plane=1000.0,
-                 eps2d=0.3, antialiasing=True, return_unstable=False):
+                 eps2d=0.3, antialiasing=True, return_unstable=False, unstable_cond=0.0, return_cond_bound=False):
     """Restates render_kernel_gsplat's forward (one camera).  opacities f32[N,1] or [N]."""
     radii, means2d, depths, conics, comps = fully_fused_projection(
         means, quats, scales, viewmat, K, width, height, eps2d=eps2d,
@@ -467,13 +501,16 @@ def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, 
     cols = np.maximum(cols + F32(0.5), F32(0.0))
     cols4 = np.concatenate([cols, depths[:, None]], axis=-1)
     res = rasterize_to_pixels(means2d[None], conics[None], cols4[None], opac[None], width, height,
-                              tile_size, offsets, flatten_ids, return_unstable=return_unstable)
+                              tile_size, offsets, flatten_ids, return_unstable=return_unstable,
+                              unstable_cond=unstable_cond, return_cond_bound=return_cond_bound)
     out = dict(radii=radii, means2d=means2d, depths=depths, conics=conics, compensations=comps,
                opacities=opac, tiles_per_gauss=tpg[0], isect_ids=isect_ids,
                flatten_ids=flatten_ids, isect_offsets=offsets, colors=cols4,
                render_colors=res[0], render_alphas=res[1], last_ids=res[2])
     if return_unstable:
         out["unstable"] = res[3]
+    if len(res) > 4:
+        out["cond_bound"] = res[4]
     return out
 
 

@@ -328,15 +328,29 @@ void sco_spherical_harmonics(int degree, const float* dirs, const float* coeffs,
 }
 
 /* ---- a9 rasterize_to_pixels forward (renderer.py:267-280; gsplat_oracle.py:344-444) */
-void sco_rasterize(const float* means2d, const float* conics, const float* colors, const float* opacities,
+void sco_rasterize_cond(const float* means2d, const float* conics, const float* colors, const float* opacities,
                    const float* backgrounds /* [C,D] nullable */, int C, int64_t N, int D, int width, int height,
                    int tile_size, int tile_width, int tile_height, const int32_t* isect_offsets,
                    const int32_t* flatten_ids, int64_t n_isects, float* render_colors, float* render_alphas,
-                   int32_t* last_ids /* nullable */, uint8_t* unstable /* [C,H,W] nullable */, float unstable_rel) {
+                   int32_t* last_ids /* nullable */, uint8_t* unstable /* [C,H,W] nullable */, float unstable_rel,
+                   float unstable_cond, float* cond_bound /* [C,H,W] nullable; needs unstable and unstable_cond > 0 */) {
     /* `unstable`: pixels where some alpha / sigma / transmittance the walk looked at sits within
      * `unstable_rel` of a hard threshold, so that a 1-ulp change of exp() may legitimately flip the skip /
-     * terminate decision (same rule as gsplat_oracle.rasterize_to_pixels(return_unstable=True)) */
+     * terminate decision (same rule as gsplat_oracle.rasterize_to_pixels(return_unstable=True)).
+     * `unstable_cond` > 0 widens the windows by the rounding-error bound of the quantities themselves:
+     * sigma is a sum of terms of magnitude S = (|A| dx^2 + |C| dy^2) / 2 + |B dx dy|, so another evaluation
+     * order moves it by about unstable_cond * 2^-24 * S (a big rotated splat has S >> sigma), alpha by that
+     * relative amount, and the transmittance by the accumulated relative errors of its factors.
+     * The byte written is a code: bit 0 = flagged under the fixed windows alone (what unstable_cond = 0 flags),
+     * bit 1 = flagged at all; non-zero == unstable.
+     * `cond_bound` receives, per pixel, the first-order bound of what that same rounding error does to the blend
+     * itself (no threshold involved): sum_i vis_i * (ea_i + 3 eps + terr_i) + T * terr, with ea_i the bound of
+     * alpha_i's relative error and terr_i that of the transmittance up to and including splat i -- in units of the colour
+     * scale.  Giant splats seen from close by (sigma's terms in the hundreds, sigma itself ~ 1) reach 1e-4 with it:
+     * there fp32 itself, not the implementation, limits the agreement of two evaluation orders. */
     (void)N;
+    const float EPS24 = 0x1p-24f;
+    const float ce = unstable_cond > 0.0f ? unstable_cond * EPS24 : 0.0f;
     const int64_t n_tiles = (int64_t)C * tile_width * tile_height;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t tflat = 0; tflat < n_tiles; ++tflat) {
@@ -355,6 +369,8 @@ void sco_rasterize(const float* means2d, const float* conics, const float* color
                 float T = 1.0f;
                 int32_t cur = 0;
                 int unst = 0;
+                float terr = 0.0f;          /* accumulated relative error bound of T (unstable_cond > 0 only) */
+                float bsum = 0.0f;          /* cond_bound's sum */
                 for (int d = 0; d < D; ++d) acc[d] = 0.0f;
                 for (int64_t k = start; k < end; ++k) {
                     const int64_t g = flatten_ids[k];
@@ -363,13 +379,31 @@ void sco_rasterize(const float* means2d, const float* conics, const float* color
                     const float sigma = 0.5f * ((ca * dx) * dx + (cc * dy) * dy) + (cb * dx) * dy;
                     const float e = opacities[g] * expf(-sigma);
                     const float alpha = e != e ? e : (e < ALPHA_MAX ? e : ALPHA_MAX);
-                    if (unstable && ((fabsf(alpha - ALPHA_MIN) <= unstable_rel * ALPHA_MIN) || (fabsf(sigma) <= 1e-6f)))
-                        unst = 1;
+                    float wa = unstable_rel, ws = 1e-6f, ea = 0.0f;
+                    if (unstable && ce > 0.0f) {
+                        const float S = 0.5f * (fabsf((ca * dx) * dx) + fabsf((cc * dy) * dy)) + fabsf((cb * dx) * dy);
+                        ea = ce * S;                 /* error bound of sigma == relative error bound of alpha */
+                        wa = unstable_rel + ea;
+                        ws = 1e-6f + ea;
+                    }
+                    if (unstable && ((fabsf(alpha - ALPHA_MIN) <= wa * ALPHA_MIN) || (fabsf(sigma) <= ws))) {
+                        unst |= 2;
+                        if ((fabsf(alpha - ALPHA_MIN) <= unstable_rel * ALPHA_MIN) || (fabsf(sigma) <= 1e-6f)) unst |= 1;
+                    }
                     if ((sigma < 0.0f) || (alpha < ALPHA_MIN) || (alpha != alpha)) continue;
                     const float Tn = T * (1.0f - alpha);
-                    if (unstable && (fabsf(Tn - T_EPS) <= (unstable_rel * 10.0f) * T_EPS)) unst = 1;
+                    float wt = unstable_rel * 10.0f;
+                    if (unstable && ce > 0.0f) {
+                        terr = terr + ((alpha * (ea + 3.0f * EPS24)) / (1.0f - alpha) + EPS24);
+                        wt = unstable_rel * 10.0f + terr;
+                    }
+                    if (unstable && (fabsf(Tn - T_EPS) <= wt * T_EPS)) {
+                        unst |= 2;
+                        if (fabsf(Tn - T_EPS) <= (unstable_rel * 10.0f) * T_EPS) unst |= 1;
+                    }
                     if (Tn <= T_EPS) break;
                     const float vis = alpha * T;
+                    if (unstable && ce > 0.0f) bsum = bsum + vis * ((ea + 3.0f * EPS24) + terr);
                     const float* c = colors + (size_t)g * D;
                     for (int d = 0; d < D; ++d) acc[d] = acc[d] + c[d] * vis;
                     cur = (int32_t)k;
@@ -381,6 +415,17 @@ void sco_rasterize(const float* means2d, const float* conics, const float* color
                 render_alphas[pix] = 1.0f - T;
                 if (last_ids) last_ids[pix] = cur;
                 if (unstable) unstable[pix] = (uint8_t)unst;
+                if (cond_bound) cond_bound[pix] = bsum + T * terr;
             }
     }
+}
+
+void sco_rasterize(const float* means2d, const float* conics, const float* colors, const float* opacities,
+                   const float* backgrounds, int C, int64_t N, int D, int width, int height, int tile_size,
+                   int tile_width, int tile_height, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                   int64_t n_isects, float* render_colors, float* render_alphas, int32_t* last_ids, uint8_t* unstable,
+                   float unstable_rel) {
+    sco_rasterize_cond(means2d, conics, colors, opacities, backgrounds, C, N, D, width, height, tile_size, tile_width,
+                       tile_height, isect_offsets, flatten_ids, n_isects, render_colors, render_alphas, last_ids,
+                       unstable, unstable_rel, 0.0f, NULL);
 }

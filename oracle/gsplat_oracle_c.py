@@ -40,6 +40,8 @@ def load(build_if_missing=True):
     lib.sco_spherical_harmonics.restype = None
     lib.sco_rasterize.argtypes = [P, P, P, P, P, i32, i64, i32, i32, i32, i32, i32, i32, P, P, i64, P, P, P, P, f32]
     lib.sco_rasterize.restype = None
+    lib.sco_rasterize_cond.argtypes = lib.sco_rasterize.argtypes + [f32, P]
+    lib.sco_rasterize_cond.restype = None
     _lib = lib
     return lib
 
@@ -103,8 +105,13 @@ def spherical_harmonics(degree, dirs, coeffs, masks=None):
 
 
 def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_height, tile_size, isect_offsets,
-                        flatten_ids, backgrounds=None, return_unstable=False, unstable_rel=2e-5):
-    """-> (render_colors [C,H,W,D], render_alphas [C,H,W,1], last_ids [C,H,W][, unstable bool[C,H,W]])."""
+                        flatten_ids, backgrounds=None, return_unstable=False, unstable_rel=2e-5, unstable_cond=0.0,
+                        return_cond_bound=False):
+    """-> (render_colors [C,H,W,D], render_alphas [C,H,W,1], last_ids [C,H,W][, unstable bool[C,H,W]]).
+    unstable_cond: see gsplat_oracle.rasterize_to_pixels.  return_unstable="codes": the flags as u8 codes
+    (bit 0 = unstable under the fixed windows alone, bit 1 = unstable at all) instead of bool.
+    return_cond_bound (with return_unstable and unstable_cond > 0): appends f32[C,H,W], the first-order bound of the
+    blend's own rounding error per pixel, in units of the colour scale."""
     lib = load()
     m2, con = _c(means2d, np.float32), _c(conics, np.float32)
     col, op = _c(colors, np.float32), _c(opacities, np.float32)
@@ -118,16 +125,19 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
     rc, ra = np.empty((Cn, H, W, D), np.float32), np.empty((Cn, H, W, 1), np.float32)
     last = np.empty((Cn, H, W), np.int32)
     unst = np.zeros((Cn, H, W), np.uint8) if return_unstable else None
-    lib.sco_rasterize(_p(m2), _p(con), _p(col), _p(op), _p(bg), Cn, N, D, W, H, int(tile_size), tw, th, _p(off),
-                      _p(fids), fids.shape[0], _p(rc), _p(ra), _p(last), _p(unst), float(unstable_rel))
+    cb = np.zeros((Cn, H, W), np.float32) if (return_cond_bound and return_unstable and unstable_cond > 0) else None
+    lib.sco_rasterize_cond(_p(m2), _p(con), _p(col), _p(op), _p(bg), Cn, N, D, W, H, int(tile_size), tw, th, _p(off),
+                           _p(fids), fids.shape[0], _p(rc), _p(ra), _p(last), _p(unst), float(unstable_rel),
+                           float(unstable_cond), _p(cb))
     if return_unstable:
-        return rc, ra, last, unst.astype(bool)
+        u = unst if return_unstable == "codes" else unst.astype(bool)
+        return (rc, ra, last, u, cb) if cb is not None else (rc, ra, last, u)
     return rc, ra, last
 
 
 def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree, cam_center=None,
                  tile_size=16, near_plane=0.001, far_plane=1000.0, eps2d=0.3, antialiasing=True,
-                 return_unstable=False):
+                 return_unstable=False, unstable_cond=0.0, return_cond_bound=False):
     """The caller's sequence (renderer.py:186-302), same outputs as gsplat_oracle.render_frame."""
     radii, m2, d, con, comp = fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2d=eps2d,
                                                      near_plane=near_plane, far_plane=far_plane)
@@ -144,9 +154,12 @@ def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, 
     cols = np.maximum(cols + np.float32(0.5), np.float32(0.0))
     cols4 = np.concatenate([cols, d[:, None]], axis=-1)
     res = rasterize_to_pixels(m2[None], con[None], cols4[None], opac[None], width, height, tile_size, off, fids,
-                              return_unstable=return_unstable)
+                              return_unstable=return_unstable, unstable_cond=unstable_cond,
+                              return_cond_bound=return_cond_bound)
     rc, ra, last = res[:3]
     extra = {"unstable": res[3]} if return_unstable else {}
+    if len(res) > 4:
+        extra["cond_bound"] = res[4]
     return dict(**extra, radii=radii, means2d=m2, depths=d, conics=con, compensations=comp, opacities=opac,
                 tiles_per_gauss=tpg[0], isect_ids=ids, flatten_ids=fids, isect_offsets=off, colors=cols4,
                 render_colors=rc, render_alphas=ra, last_ids=last)

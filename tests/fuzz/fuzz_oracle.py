@@ -1,7 +1,9 @@
 """Randomised GPU-vs-ORACLE check of the caller's sequence at sizes the numpy oracle is too slow for: the C / OpenMP
 restatement (oracle/gsplat_oracle_c.c, pinned bit for bit to the numpy oracle by tests/test_oracle_cpu.py) against
 the HIP path.  Integer outputs and projection / SH floats bit-exact; pixels within 1e-4 on the pixels the oracle does
-not flag threshold-unstable.  (tools/fuzz_paths.py compares the GPU paths with each other; this one compares them
+not flag threshold-unstable (+ the oracle's own rounding bound per pixel) -- flagged with the CONDITIONED window (unstable_cond = 8: the fixed 2e-5 window of the
+committed fixtures plus 8 x 2^-24 x the magnitude of sigma's terms, see gsplat_oracle.rasterize_to_pixels); the count
+of outliers under the fixed window is printed beside it.  (tools/fuzz_paths.py compares the GPU paths with each other; this one compares them
 with the checker.)  Test infrastructure (it uses oracle/): lives under tests/, never imported by the product.
 Usage: python tests/fuzz/fuzz_oracle.py [seed] [rounds]"""
 import os
@@ -42,30 +44,39 @@ for it in range(ROUNDS):
             o = render_gaussians(sc.to("cuda"), cam.to("cuda"), return_intermediates=True)
     torch.cuda.synchronize()
     ref = OC.render_frame(sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(), sc.sh.numpy(),
-                          cam.viewmat.numpy(), cam.K.numpy(), W, H, deg, return_unstable=True)
+                          cam.viewmat.numpy(), cam.K.numpy(), W, H, deg, return_unstable="codes", unstable_cond=8.0,
+                          return_cond_bound=True)
     g = lambda k: o[k].detach().cpu().numpy()       # noqa: E731
     ints_ok = (np.array_equal(g("_radii")[0], ref["radii"]) and np.array_equal(g("_tiles_per_gauss")[0], ref["tiles_per_gauss"])
                and np.array_equal(g("_flatten_ids"), ref["flatten_ids"]) and np.array_equal(g("_isect_offsets"), ref["isect_offsets"])
                and np.array_equal(g("_isect_ids"), ref["isect_ids"]))
     floats_ok = all(np.array_equal(g(a)[0].view(np.uint32), ref[b].view(np.uint32))
                     for a, b in (("_means2d", "means2d"), ("_depths", "depths"), ("_conics", "conics")))
-    stable = ~ref["unstable"][0]
+    stable = ref["unstable"][0] == 0
+    fixed = (ref["unstable"][0] & 1) == 0          # stable under the fixtures' fixed 2e-5 window alone
     rc = g("_render_colors")[0]
     scale = np.maximum(1.0, np.abs(ref["render_colors"][0]).max(axis=(0, 1)))          # depth channel is in metres
     err = (np.abs(rc - ref["render_colors"][0]) / scale)[stable].max() if stable.any() else 0.0
     aerr = np.abs(g("_render_alphas")[0] - ref["render_alphas"][0])[stable].max() if stable.any() else 0.0
-    # pixels beyond 1e-4 although the oracle calls them stable: its window around the hard thresholds is a fixed 2e-5
-    # relative, but the rounding error of sigma = (A dx^2 + C dy^2) / 2 + B dx dy grows with the splat (cancellation
-    # between the terms of a big rotated splat): one alpha-threshold flip moves a pixel by up to 1/255
+    # per-pixel bar: 1e-4 + the oracle's first-order bound of the blend's own rounding error (sigma's terms reach the
+    # hundreds for giant splats seen from close by while sigma ~ 1: two fp32 evaluation orders then differ by more than
+    # 1e-4 whatever the implementation; the bound is < 1e-5 for ordinary scenes, 5e-4 in the worst configuration drawn)
+    bound = 0.25 * ref["cond_bound"][0]       # the oracle's bound is for 8 ulp of sigma's terms: 2 ulp here
     e_pix = (np.abs(rc - ref["render_colors"][0]) / scale).max(axis=-1)
-    n_over = int(((e_pix > 1e-4) & stable).sum())
-    ok = ints_ok and floats_ok and n_over <= max(2, int(1e-4 * stable.size)) and err <= 5e-3 and aerr <= 5e-3
+    a_pix = np.abs(g("_render_alphas")[0] - ref["render_alphas"][0])[..., 0]
+    n_over = int(((np.maximum(e_pix, a_pix) > 1e-4 + bound) & stable).sum())
+    n_over_plain = int(((e_pix > 1e-4) & stable).sum())
+    # the same count under the fixtures' fixed 2e-5 window, which under-flags big rotated splats
+    n_over_fixed = int(((e_pix > 1e-4) & fixed).sum())
+    ok = ints_ok and floats_ok and n_over == 0
     print(f"[{it}] N={n} {W}x{H} deg={deg} smax={smax} z>={zmin} f={f:.0f} yaw={yaw} I={ref['flatten_ids'].size}: ints "
           f"{'ok' if ints_ok else 'MISMATCH'}, projection floats {'ok' if floats_ok else 'MISMATCH'}, pixels {err:.2e} / alpha "
-          f"{aerr:.2e} on {stable.mean() * 100:.2f} % stable, {n_over} stable pixels over 1e-4: {'ok' if ok else 'FAIL'}", flush=True)
+          f"{aerr:.2e} on {stable.mean() * 100:.2f} % stable, rounding bound <= {float(bound[stable].max()) if stable.any() else 0:.1e}, "
+          f"{n_over_plain} stable pixels over a flat 1e-4 ({n_over_fixed} under the fixed window, "
+          f"{fixed.mean() * 100:.2f} % stable): {'ok' if ok else 'FAIL'}", flush=True)
     if not ok:
-        py, px = np.unravel_index(np.argmax(np.where(stable, e_pix, 0.0)), e_pix.shape)
-        print(f"    worst stable pixel ({px}, {py}): GPU {rc[py, px].tolist()} oracle {ref['render_colors'][0][py, px].tolist()} "
+        py, px = np.unravel_index(np.argmax(np.where(stable, np.maximum(e_pix, a_pix) - bound, -1.0)), e_pix.shape)
+        print(f"    worst stable pixel ({px}, {py}), rounding bound {float(bound[py, px]):.2e}: GPU {rc[py, px].tolist()} oracle {ref['render_colors'][0][py, px].tolist()} "
               f"alpha {float(g('_render_alphas')[0][py, px, 0]):.7f} / {float(ref['render_alphas'][0][py, px, 0]):.7f}; last blended "
               f"index oracle {int(ref['last_ids'][0][py, px])}, tile list "
               f"{int(ref['isect_offsets'].reshape(-1)[(py // 16) * ((W + 15) // 16) + px // 16])}..")

@@ -266,6 +266,33 @@ def test_c_oracle_is_pinned_to_the_numpy_oracle(case):
     np.testing.assert_array_equal(gg[2], ee[2])
 
 
+def test_conditioned_instability_window_widens_the_flags_and_both_oracles_agree():
+    """`unstable_cond` > 0: the threshold windows grow with the rounding-error bound of sigma (big rotated splats).
+    Both restatements flag the same pixels, the default flags are a subset, images are untouched."""
+    from oracle import gsplat_oracle_c as OC
+    sc = make_scene(1500, sh_degree=1, seed=77, z_range=(0.5, 20.0), scale_range=(0.01, 1.5))
+    cam = make_camera(200, 120, 280.0, 280.0)
+    a = (sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(), sc.sh.numpy(),
+         cam.viewmat.numpy(), cam.K.numpy(), cam.width, cam.height, 1)
+    OC.set_num_threads(3)
+    base = OC.render_frame(*a, return_unstable=True)
+    wide = OC.render_frame(*a, return_unstable=True, unstable_cond=8.0, return_cond_bound=True)
+    wide_np = O.render_frame(*a, return_unstable=True, unstable_cond=8.0, return_cond_bound=True)
+    np.testing.assert_array_equal(wide["unstable"], wide_np["unstable"])
+    # the blend's own first-order rounding bound: same in both, small for ordinary splats, and it covers what the two
+    # restatements (libm's expf vs numpy's) actually differ by
+    np.testing.assert_allclose(wide["cond_bound"], wide_np["cond_bound"], rtol=1e-4, atol=1e-9)
+    assert 0 < wide["cond_bound"].max() < 1e-4
+    codes = OC.render_frame(*a, return_unstable="codes", unstable_cond=8.0)["unstable"]
+    np.testing.assert_array_equal((codes & 1) > 0, base["unstable"])
+    np.testing.assert_array_equal(codes > 0, wide["unstable"])
+    assert not (base["unstable"] & ~wide["unstable"]).any()
+    assert wide["unstable"].sum() > base["unstable"].sum()
+    assert wide["unstable"].mean() < 0.05
+    for k in ("render_colors", "render_alphas"):
+        np.testing.assert_array_equal(base[k].view(np.uint32), wide[k].view(np.uint32))
+
+
 def test_two_pass_composite_and_quantisation_restatement():
     """composite_sky / quantise_u8 are the reference's expressions (renderer.py:152,159; visualizer :92,:97)."""
     rng = np.random.default_rng(9)
