@@ -402,6 +402,8 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     //     the XCD that owns the dense band finishes long after the others: 0.49 vs 0.33 ms on the street scene,
     //     no difference on the uniform S-1M).
     int tflat = blockIdx.x, kind = 0;
+    if (order && tile_work)      // the hint bank of this call's view: the slot is the list's last word (uniform load)
+        tile_work += (size_t)sc_clamp_view_slot(order[total_tiles + total_tiles / 8 + 8 + total_tiles + 1]) * total_tiles;
     if (order) {
         // an ITEM of the dispatch list (include/street_crafter_amd.h, sc_tile_order_len): tile << 2 | kind, kind 0 =
         // the whole tile, 1 / 2 = its upper / lower 16 x 8 half (two waves share a tile whose walk would otherwise be
@@ -441,9 +443,9 @@ int g_sc_raster_split = 50;   // sc_set_option "raster_split": tiles with >= thi
 int sc_tile_order_fwd_items(int total_tiles) { return total_tiles + total_tiles / 8 + 8; }
 
 // Length of the dispatch-list buffer: the forward's list, then the whole-tile list (same order; built only under
-// raster_bwd_split 0) and a word that says whether it is there.
+// raster_bwd_split 0), a word that says whether it is there, and the view slot of the call (sc_common.h).
 extern "C" int sc_tile_order_len(int total_tiles) {
-    return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles + 1;     // + "second list present"
+    return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles + 2;     // + "second list present" + view slot
 }
 
 extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {

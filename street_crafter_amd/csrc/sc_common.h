@@ -25,6 +25,13 @@
 // computation of counts / offsets other code indexes with, and bound-check at the consumer anyway.
 extern int g_sc_debug[4];
 extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
+// VIEW SLOTS: the rasterizer's work hint is kept per VIEW (a street rig renders front / front-left / front-right in
+// turn: a frame must not find the hint another camera left).  sc_view_slot_pick (isect_bin.hip) matches camera 0's
+// forward axis against a small device-side registry and hands the call a slot number; the hint buffer is
+// SC_VIEW_SLOTS banks of C * T words, and the slot travels to the rasterizer in the last word of the dispatch list.
+constexpr int SC_VIEW_SLOTS = 8;
+constexpr int SC_VIEW_REGISTRY_WORDS = 4 + 4 * SC_VIEW_SLOTS;   // [0] call counter; per slot: forward axis (3 floats), stamp
+__host__ __device__ static inline int sc_clamp_view_slot(int v) { return v < 0 ? 0 : (v >= SC_VIEW_SLOTS ? SC_VIEW_SLOTS - 1 : v); }
 extern int g_sc_raster_bwd_split;    // sc_set_option "raster_bwd_split" (raster_bwd.hip)
 extern int g_sc_raster_hint_blend;   // sc_set_option "raster_hint_blend"
 extern int g_sc_raster_split;   // sc_set_option "raster_split" (raster_fwd.hip; read by the order job of isect_bin.hip)

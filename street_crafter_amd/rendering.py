@@ -180,6 +180,10 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
     assert Ks.shape == (C, 3, 3), Ks.shape
     out = _call(_Projection, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                             far_plane, radius_clip, calc_compensations)
+    if N:
+        slot = _pick_view_slot(viewmats, _stream(means))
+        if slot is not None:
+            out[1]._sc_view_slot = slot          # means2d carries the call's view slot to isect_tiles
     if calc_compensations:
         return out
     return (*out, None)
@@ -197,6 +201,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     if packed:
         raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
     lib = _lib.load()
+    view_slot = getattr(means2d, "_sc_view_slot", None)
     means2d = _req(means2d.detach(), "means2d")
     radii = _req(radii, "radii", torch.int32)
     depths = _req(depths.detach(), "depths")
@@ -212,7 +217,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     mode = _ISECT_MODE["mode"] if sort else "radix"
     if mode == "bin":
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, total_dev, st)
+                               tiles_per_gauss, total_dev, st, view_slot=view_slot)
         if res is not None:
             return res[:3]
     wsb = lib.sc_isect_workspace_bytes(C * N)
@@ -254,10 +259,12 @@ def _check_isect_count(n_isects, C, N, tile_width, tile_height):
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
-_TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [C * tiles]: the list entries every tile
+_TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [view slots, C * tiles]: the list entries every tile
                        # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
 _TILE_ORDER = {"on": True}
 _LAZY_ISECT_IDS = {"on": True}
+_VIEW_SLOTS = {"on": True}
+_VIEW_REGISTRY = {}    # device index -> int32 [sc_view_registry_words()]: the device-side table forward axis -> view slot
 
 
 def set_tile_order(enabled: bool) -> bool:
@@ -267,6 +274,29 @@ def set_tile_order(enabled: bool) -> bool:
     return prev
 
 
+def set_view_slots(enabled: bool) -> bool:
+    """The rasterizer's work hint per VIEW (A/B switch; results are identical either way): a rig's cameras rendered
+    in turn each find the hint their own last frame left.  Returns the previous setting."""
+    prev, _VIEW_SLOTS["on"] = _VIEW_SLOTS["on"], bool(enabled)
+    return prev
+
+
+def _pick_view_slot(viewmats: Tensor, st) -> Optional[Tensor]:
+    """int32[1] on the device: the view slot of camera 0 (sc_view_slot_pick: matched on the device against a small
+    registry of forward axes, no host round trip), or None when the dispatch list / the slots are off.  The
+    projection wrappers attach it to `means2d`, which carries it to isect_tiles."""
+    if not (_VIEW_SLOTS["on"] and _TILE_ORDER["on"]) or viewmats.shape[0] == 0:
+        return None
+    lib = _lib.load()
+    dev = viewmats.device
+    reg = _VIEW_REGISTRY.get(dev.index)
+    if reg is None:
+        reg = _VIEW_REGISTRY[dev.index] = torch.zeros(lib.sc_view_registry_words(), dtype=torch.int32, device=dev)
+    slot = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.sc_view_slot_pick(_p(viewmats), int(viewmats.shape[0]), _p(reg), _p(slot), st), "sc_view_slot_pick")
+    return slot
+
+
 def _tile_work(dev, C, N, tile_width, tile_height) -> Tensor:
     """The rasterizer's per-tile work hint of this frame shape AND Gaussian count: the foreground and the sky pass
     of a novel-view frame have the same frame shape and must not feed each other's dispatch list.  At most 8
@@ -274,7 +304,9 @@ def _tile_work(dev, C, N, tile_width, tile_height) -> Tensor:
     key = (dev.index, int(C), int(N), int(tile_width), int(tile_height))
     t = _TILE_WORK.pop(key, None)
     if t is None:
-        t = torch.zeros(int(C) * int(tile_width) * int(tile_height), dtype=torch.int32, device=dev)
+        # one bank of C * tiles words per view slot (the kernels pick the bank: sc_common.h)
+        t = torch.zeros(_lib.load().sc_view_slots() * int(C) * int(tile_width) * int(tile_height), dtype=torch.int32,
+                        device=dev)
         while len(_TILE_WORK) >= 8:
             _TILE_WORK.pop(next(iter(_TILE_WORK)))
     _TILE_WORK[key] = t                  # (re-inserted: dicts keep insertion order, the first key is the oldest)
@@ -303,7 +335,7 @@ def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                     tiles_per_gauss, total_dev, st, want_ids=True):
+                     tiles_per_gauss, total_dev, st, want_ids=True, view_slot=None):
     """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
     the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
     rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
@@ -335,7 +367,9 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
                                 meta_host.data_ptr(), seq, _p(ws0), ws0.numel(),
-                                None if sched is None else _p(sched[1]), None if sched is None else _p(sched[0]), st)
+                                None if sched is None else _p(sched[1]),
+                                None if (sched is None or view_slot is None or view_slot.device != dev) else _p(view_slot),
+                                None if sched is None else _p(sched[0]), st)
     if sched is not None:
         offsets._sc_sched = sched          # travels with isect_offsets to rasterize_to_pixels
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
@@ -492,7 +526,7 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 def _sched_of(isect_offsets, n_tiles):
     """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
     sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
-    if (sched is None or sched[1].numel() != n_tiles or sched[0].device != isect_offsets.device
+    if (sched is None or sched[1].numel() != _lib.load().sc_view_slots() * n_tiles or sched[0].device != isect_offsets.device
             or sched[0].numel() != _lib.load().sc_tile_order_len(n_tiles)):
         return None, None
     return sched
@@ -693,13 +727,14 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                                         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                         int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
                                         _p(opac), _p(cols), st), "sc_projection_sh_fwd")
+    view_slot = _pick_view_slot(viewmats, st) if N else None
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     res = None
     if _ISECT_MODE["mode"] == "bin":
         tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, None, st, want_ids=False)
+                               tiles_per_gauss, None, st, want_ids=False, view_slot=view_slot)
     if res is not None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = res
     else:

@@ -76,7 +76,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_rasterize_fwd_ed(None, None, None, None, None, None, 1, 4, 3, 64, 64, 16, 4, 4,
                                    None, None, 0, None, None, None, None, None, 0, None) in (-1, -3)   # needs D == 4
     assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None, None,
-                                  None) == -1
+                                  None, None) == -1
+    assert lib.sc_view_slot_pick(None, 1, None, None, None) == -1
+    assert lib.sc_view_slots() == 8 and lib.sc_view_registry_words() == 4 + 4 * 8
     assert lib.sc_knn3_mean_dist2(None, 0, None, None, 0, None) == 0
     assert lib.sc_knn_workspace_bytes(1000) >= 1000 * 36
     assert lib.sc_isect_workspace_bytes(1_000_000) >= (1_000_000 // 256) * 8
@@ -106,7 +108,7 @@ def test_host_side_waits_and_list_sizes(lib):
     assert lib.sc_wait_i64(addr, 9, 5_000_000) == 0                 # the waiting call holds no GIL: the thread runs
     th.join()
     for tiles in (0, 1, 6, 425, 9600, 36864):
-        assert lib.sc_tile_order_len(tiles) == (tiles + tiles // 8 + 8) + tiles + 1
+        assert lib.sc_tile_order_len(tiles) == (tiles + tiles // 8 + 8) + tiles + 2
     assert lib.sc_tile_order_len(-3) == 0
     for key in (b"raster_split", b"raster_hint_blend", b"raster_bwd_split", b"raster_map"):
         prev = lib.sc_set_option(key, 0)
@@ -117,14 +119,14 @@ def test_host_side_waits_and_list_sizes(lib):
 def test_work_hint_buffers_are_keyed_and_bounded():
     """The rasterizer's per-tile work hints: one buffer per (device, cameras, Gaussian count, tile grid) -- the two
     passes of a novel-view frame must not share one -- and at most 8 of them (densification changes N)."""
-    from street_crafter_amd import rendering
+    from street_crafter_amd import _lib, rendering
     rendering._TILE_WORK.clear()
     dev = torch.device("cpu")
     a = rendering._tile_work(dev, 1, 1000, 4, 3)
     b = rendering._tile_work(dev, 1, 31, 4, 3)
-    assert a.shape == b.shape == (12,) and a.data_ptr() != b.data_ptr() and a.dtype == torch.int32
+    assert a.shape == b.shape == (12 * _lib.load().sc_view_slots(),) and a.data_ptr() != b.data_ptr() and a.dtype == torch.int32
     assert rendering._tile_work(dev, 1, 1000, 4, 3).data_ptr() == a.data_ptr()
-    assert rendering._tile_work(dev, 2, 1000, 4, 3).shape == (24,)
+    assert rendering._tile_work(dev, 2, 1000, 4, 3).shape == (24 * _lib.load().sc_view_slots(),)
     for n in range(2000, 2010):
         rendering._tile_work(dev, 1, n, 4, 3)
     assert len(rendering._TILE_WORK) == 8

@@ -1065,17 +1065,21 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
     n_tiles = n_cams * (w // 16) * (h // 16)
     rendering._TILE_WORK.clear()
     from scipy.ndimage import maximum_filter
-    split_counts = []
+    split_counts, slots_seen = [], []
     for which in (0, 0, 1, 0):          # cold, warm, stale hint from scene 0, stale hint from scene 1
         torch.cuda.synchronize()
-        hint = _np(rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), n_cams, scenes[which].n, w // 16,
-                                        h // 16)).copy()
+        banks = _np(rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), n_cams, scenes[which].n, w // 16,
+                                         h // 16)).copy().reshape(-1, n_tiles)
         rc, ra, meta = render(scenes[which])
         order, work = meta["isect_offsets"]._sc_sched
         torch.cuda.synchronize()
         o = _np(order)
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
-        assert o[-1] == 0        # the whole-tile list behind the forward's is built under raster_bwd_split 0 only
+        assert o[-2] == 0        # the whole-tile list behind the forward's is built under raster_bwd_split 0 only
+        slot = int(o[-1])        # the view slot of the call: which bank of the hint buffer this view reads and writes
+        assert 0 <= slot < banks.shape[0] == _lib.load().sc_view_slots()
+        slots_seen.append(slot)
+        hint = banks[slot]
         o = o[: n_tiles + n_tiles // 8 + 8]                                            # the forward's list
         n_items = int((o >= 0).sum())
         assert (o[:n_items] >= 0).all() and (o[n_items:] == -1).all()          # padding at the end only
@@ -1114,10 +1118,14 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         # what the kernel reported: entries walked (+8 per staged batch), zero exactly where the tile list is empty
         offs = _np(meta["isect_offsets"]).reshape(-1).astype(np.int64)
         counts = np.diff(np.concatenate([offs, [meta["flatten_ids"].numel()]]))
-        wk = _np(work)
+        wk = _np(work).reshape(-1, n_tiles)
+        others = np.arange(wk.shape[0]) != slot
+        np.testing.assert_array_equal(wk[others], banks[others])          # the other views' banks are left alone
+        wk = wk[slot]
         assert ((wk == 0) == (counts == 0)).all()
         assert (wk <= counts + 8 * ((counts + 63) // 64 + 1)).all()
         assert wk.max() > 50
+    assert len(set(slots_seen)) == 1                                   # one view: one slot
     assert split_counts[0] == 0 and max(split_counts[1:]) > 0          # no hint: nothing is split
     n_fwd = n_tiles + n_tiles // 8 + 8
     # raster_bwd_split 0: the whole-tile list for the backward is built too -- the same tiles in the same order
@@ -1127,7 +1135,7 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         o = _np(meta["isect_offsets"]._sc_sched[0])
     finally:
         _lib.set_option("raster_bwd_split", prev_b)
-    assert o[-1] == 1
+    assert o[-2] == 1
     fwd = o[:n_fwd][o[:n_fwd] >= 0]
     np.testing.assert_array_equal(o[n_fwd:n_fwd + n_tiles], (fwd[(fwd & 3) != 2] >> 2) << 2)
     prev = _lib.set_option("raster_split", 0)
@@ -1168,6 +1176,7 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
         rc, ra, meta = render()
         o = _np(meta["isect_offsets"]._sc_sched[0])
         assert o.shape == (_lib.load().sc_tile_order_len(n_tiles),)
+        assert 0 <= o[-1] < _lib.load().sc_view_slots()
         o = o[: n_tiles + n_tiles // 8 + 8]
         items = o[o >= 0]
         assert (o[: items.size] >= 0).all()
@@ -1202,7 +1211,8 @@ def test_tile_dispatch_list_survives_any_hint_values(ops, fill):
     finally:
         rendering.set_tile_order(prev)
     n_tiles = (w // 16) * (h // 16)
-    hint = rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), 1, n, w // 16, h // 16)
+    # [view slots, tiles]: every bank gets the pattern, whichever slot this view is filed under
+    hint = rendering._tile_work(torch.device(DEV, torch.cuda.current_device()), 1, n, w // 16, h // 16).view(-1, n_tiles)
     g = torch.Generator(device=DEV).manual_seed(3)
     if fill == "random":
         hint.copy_(torch.randint(-2**31, 2**31 - 1, (n_tiles,), device=DEV, generator=g, dtype=torch.int64).to(torch.int32))
@@ -1212,7 +1222,7 @@ def test_tile_dispatch_list_survives_any_hint_values(ops, fill):
         hint.fill_(2**31 - 1)
     elif fill == "one_hot":
         hint.zero_()
-        hint[n_tiles // 2] = 60_000
+        hint[:, n_tiles // 2] = 60_000
     else:
         hint.copy_(torch.arange(n_tiles, device=DEV, dtype=torch.int32) * 7)
     rc, ra, meta = render()
@@ -1225,6 +1235,80 @@ def test_tile_dispatch_list_survives_any_hint_values(ops, fill):
     np.testing.assert_array_equal(np.sort(tiles[kinds == 1]), np.sort(tiles[kinds == 2]))
     np.testing.assert_array_equal(_np(rc).view(np.uint32), _np(plain[0]).view(np.uint32))
     np.testing.assert_array_equal(_np(ra).view(np.uint32), _np(plain[1]).view(np.uint32))
+
+
+def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
+    """A rig's cameras are rendered in turn: each must find the hint ITS last frame left, not the previous call's.
+    sc_view_slot_pick files a call under a slot by camera 0's forward axis, on the device; the slot selects the bank
+    of the hint buffer that isect_tiles reads and the rasterizer writes.  Checked: three cameras get three slots and
+    keep them, a bank only changes when its own camera renders, the image never depends on any of it, a camera that
+    turns slowly keeps its slot, and a ninth view takes over the least recently used slot."""
+    from street_crafter_amd import _lib, rendering
+    from street_crafter_amd.pipeline import render_gaussians
+    from street_crafter_amd.scenes import make_street_scene
+    lib = _lib.load()
+    K_SLOTS = lib.sc_view_slots()
+    w, h, n = 640, 400, 60_000
+    T = (w // 16) * (h // 16)
+    sc = make_street_scene(n, seed=21)[0].to(DEV)
+    yaws = (0.0, 0.5, -0.5)
+    cams = [make_camera(w, h, 600.0, 600.0, yaw=y).to(DEV) for y in yaws]
+    dev = torch.device(DEV, torch.cuda.current_device())
+
+    def frame(cam):
+        with torch.no_grad():
+            o = render_gaussians(sc, cam, return_intermediates=True)
+        torch.cuda.synchronize()
+        order, work = o["_isect_offsets"]._sc_sched
+        return _np(o["_render_colors"]), int(_np(order)[-1]), _np(work).reshape(K_SLOTS, T).copy()
+
+    prev = rendering.set_view_slots(False)
+    try:
+        plain = [frame(c)[0] for c in cams]
+    finally:
+        rendering.set_view_slots(prev)
+    rendering._TILE_WORK.clear()
+    rendering._VIEW_REGISTRY.pop(dev.index, None)          # a fresh registry: slots are handed out in order
+    slots, banks = {}, np.zeros((K_SLOTS, T), np.int32)
+    for rnd in range(3):
+        for i, cam in enumerate(cams):
+            img, slot, after = frame(cam)
+            np.testing.assert_array_equal(img.view(np.uint32), plain[i].view(np.uint32))
+            assert slots.setdefault(i, slot) == slot
+            others = np.arange(K_SLOTS) != slot
+            np.testing.assert_array_equal(after[others], banks[others])
+            assert after[slot].max() > 50
+            if rnd:          # same scene, same camera: the bank already held THIS view's work (the counts of split
+                             # tiles vary with which half reports last; the empty tiles are exactly the view's)
+                np.testing.assert_array_equal(after[slot] == 0, banks[slot] == 0)
+                for j, sj in slots.items():
+                    assert j == i or ((after[slot] == 0) != (banks[sj] == 0)).sum() > 20
+            banks = after
+    assert sorted(slots.values()) == [0, 1, 2]
+    # a camera that turns by 0.05 rad per frame (far beyond the 7 degree window in total) keeps its slot
+    s0 = None
+    for k in range(12):
+        _, slot, _ = frame(make_camera(w, h, 600.0, 600.0, yaw=1.2 + 0.05 * k).to(DEV))
+        s0 = slot if s0 is None else s0
+        assert slot == s0 and slot not in slots.values()
+    # the registry itself: 8 far-apart views fill the slots, the ninth takes over the least recently used one
+    reg = torch.zeros(lib.sc_view_registry_words(), dtype=torch.int32, device=DEV)
+    out = torch.empty(1, dtype=torch.int32, device=DEV)
+
+    def pick(yaw, pitch=0.0):
+        V = torch.eye(4)
+        V[2, :3] = torch.tensor([math.sin(yaw) * math.cos(pitch), math.sin(pitch), math.cos(yaw) * math.cos(pitch)])
+        Vd = V[None].to(DEV).contiguous()
+        assert lib.sc_view_slot_pick(Vd.data_ptr(), 1, reg.data_ptr(), out.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        return int(out.item())
+
+    first = [pick(0.7 * k) for k in range(K_SLOTS)]
+    assert sorted(first) == list(range(K_SLOTS))
+    assert [pick(0.7 * k + 0.05) for k in range(K_SLOTS)] == first          # within the window: same slots
+    assert pick(0.7 * 1 + 0.05) == first[1]
+    assert pick(0.2, pitch=1.2) == first[0]                                  # new view: slot of the LRU view (k = 0)
+    assert pick(0.7 * 2 + 0.05) == first[2]                                  # the others are untouched
 
 
 def test_frame_without_gaussians_is_rendered_everywhere(ops):
