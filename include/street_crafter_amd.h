@@ -129,22 +129,22 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* 
                        void* workspace, size_t ws_bytes,
                        const int32_t* tile_work /* nullable: [sc_view_slots()][C*tile_width*tile_height], see
                            sc_rasterize_fwd */,
-                       const int32_t* view_slot /* nullable (= slot 0): device int32 written by sc_view_slot_pick: which
-                           bank of tile_work this call's view uses; stored into tile_order's last word */,
+                       const float* viewmats /* nullable (= slot 0): [C,4,4] world->camera, the frame's cameras: which
+                           bank of tile_work this call uses is looked up from camera 0's forward axis, see VIEW SLOTS */,
+                       int32_t* view_registry /* nullable (= slot 0): int32[sc_view_registry_words()], VIEW SLOTS */,
                        int32_t* tile_order /* nullable: out, the rasterizer's dispatch list built from tile_work:
                            sc_tile_order_len(C*tile_width*tile_height) items, see sc_rasterize_fwd */,
                        sc_stream_t stream);
 /* VIEW SLOTS.  The rasterizer's work hint (tile_work) only helps the frame that finds it if it was left by the
  * same view; a street rig renders front / front-left / front-right in turn.  tile_work therefore has sc_view_slots()
- * banks of C*tile_width*tile_height words, and sc_view_slot_pick chooses the bank on the DEVICE (no host round
- * trip): camera 0's forward axis (row 2 of the world->camera rotation of viewmats [C,4,4]) is matched against
- * `registry` (persistent, caller-owned, zero-initialised int32[sc_view_registry_words()], one per device); a slot
- * within ~7 degrees is reused and follows the camera, otherwise the least recently used one is taken over.
- * slot_out: device int32[1], handed to sc_isect_bin_count of the same frame.  Scheduling only: any slot value
- * renders the same image. */
+ * banks of C*tile_width*tile_height words, and sc_isect_bin_count chooses the bank on the DEVICE (no host round
+ * trip, no extra launch): camera 0's forward axis (row 2 of the world->camera rotation of viewmats [C,4,4]) is
+ * matched against `view_registry` (persistent, caller-owned, zero-initialised int32[sc_view_registry_words()], one
+ * per device); a slot within ~7 degrees is reused and follows the camera, otherwise the least recently used one
+ * is taken over.  The slot is stored in tile_order's last word, where the rasterizer finds the bank to report
+ * into.  Scheduling only: any slot renders the same image. */
 int sc_view_slots(void);
 int sc_view_registry_words(void);
-int sc_view_slot_pick(const float* viewmats, int C, int32_t* registry, int32_t* slot_out, sc_stream_t stream);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
                       const int32_t* isect_offsets, const int64_t* meta_dev,
@@ -207,7 +207,7 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
  * same order (total_tiles items `tile << 2`), one word that says whether that second list was built: it is only
  * under sc_set_option raster_bwd_split 0 (set BEFORE the frame's sc_isect_bin_count), for a backward that takes
  * whole tiles; by default sc_rasterize_bwd follows the forward's list, half tiles included -- and, last, the view
- * slot of the call (see sc_view_slot_pick). */
+ * slot of the call (see VIEW SLOTS). */
 int sc_tile_order_len(int total_tiles);
 /* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
  * with scratch needs no ABI change) */

@@ -43,11 +43,10 @@ SIGNATURES = {
                                               C.c_void_p, C.c_size_t, c_stream]),
     "sc_isect_bin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int64]),
     "sc_isect_bin_count": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p,
-                                     c_i32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, C.c_size_t, c_i32p, c_i32p, c_i32p,
-                                     c_stream]),
+                                     c_i32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, C.c_size_t, c_i32p, c_f32p, c_i32p,
+                                     c_i32p, c_stream]),
     "sc_view_slots": (C.c_int, []),
     "sc_view_registry_words": (C.c_int, []),
-    "sc_view_slot_pick": (C.c_int, [c_f32p, C.c_int, c_i32p, c_i32p, c_stream]),
     "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_i32p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i64p,
                                     c_i32p, C.c_void_p, C.c_size_t, c_stream]),

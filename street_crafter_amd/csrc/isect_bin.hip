@@ -76,6 +76,46 @@ __device__ __forceinline__ Rect super_rect(const Rect& r, int ss) {
     return s;
 }
 
+// ---- view slots (sc_common.h) ----------------------------------------------------------------------------------
+// Camera 0's forward axis (third row of the world -> camera rotation) against the registry's slots.  A slot within
+// ~7 degrees is this view's (and, with `update`, follows it: a turning camera keeps its slot); otherwise the least
+// recently used slot is taken over -- its hints are another view's, valid and only less useful, for one frame.
+// Every hint workgroup of a count launch looks the slot up for itself and ONE of them updates the registry: the
+// axis is written before the stamp, so a reader sees (old axis, old stamp) -> the same LRU slot, or the new axis
+// -> a match on that slot.  Two streams may update at the same time: every word is written whole, a mixed-up
+// entry only costs a re-pick.
+__device__ __forceinline__ int view_slot_lookup(const float* __restrict__ viewmats, unsigned* registry, bool update) {
+    float fx = viewmats[8], fy = viewmats[9], fz = viewmats[10];
+    const float inv = rsqrtf(fmaxf(fx * fx + fy * fy + fz * fz, 1e-20f));
+    fx *= inv; fy *= inv; fz *= inv;
+    const unsigned now = __hip_atomic_load(&registry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int best = -1, lru = 0;
+    float best_dot = 0.9925f;                      // cos(7 degrees)
+    unsigned lru_age = 0;
+#pragma unroll
+    for (int k = 0; k < SC_VIEW_SLOTS; ++k) {
+        unsigned e[4];                             // (agent-scope loads: another stream's launch may be updating)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            e[j] = __hip_atomic_load(&registry[4 + 4 * k + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool used = (e[0] | e[1] | e[2]) != 0u;
+        const float d = __uint_as_float(e[0]) * fx + __uint_as_float(e[1]) * fy + __uint_as_float(e[2]) * fz;
+        if (used && d > best_dot) { best_dot = d; best = k; }
+        const unsigned age = used ? now - e[3] + 1u : 0xffffffffu;
+        if (age > lru_age) { lru_age = age; lru = k; }
+    }
+    if (best < 0) best = lru;
+    if (update) {
+        unsigned* e = registry + 4 + 4 * best;
+        atomicExch(&e[0], __float_as_uint(fx) | (fx == 0.f && fy == 0.f && fz == 0.f ? 1u : 0u));
+        atomicExch(&e[1], __float_as_uint(fy));
+        atomicExch(&e[2], __float_as_uint(fz));
+        __threadfence();
+        atomicExch(&e[3], atomicAdd(&registry[0], 1u) + 1u);
+    }
+    return best;
+}
+
 // ---- pass 1: counts ---------------------------------------------------------------------------
 // dgrid_t : [C][th+1][tw+1]   2-D difference grid over tiles        (-> per-tile counts)
 // dgrid_s : [C][sth+1][stw+1] 2-D difference grid over super-tiles  (-> records per super-tile)
@@ -89,7 +129,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     float tile_size, int C, int32_t* __restrict__ tiles_per_gauss, int* __restrict__ dgrid_t,
     int* __restrict__ dgrid_s, unsigned* __restrict__ chist, int n_count_blocks,
     const int32_t* __restrict__ tile_work, unsigned* __restrict__ whint, unsigned* __restrict__ wstat, int blend,
-    const int32_t* __restrict__ view_slot, int32_t* __restrict__ slot_word) {
+    const float* __restrict__ viewmats, unsigned* view_registry, int32_t* __restrict__ slot_word) {
     extern __shared__ int lds_i[];
     if ((int)blockIdx.x >= n_count_blocks) {
         // HINT blocks (the launch has CUs to spare: ~120 count workgroups): the rasterizer's per-tile work hint for
@@ -104,7 +144,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
         const int T = g.T, tw = g.tile_width, th = g.tile_height, n = C * T;
         const int i = ((int)blockIdx.x - n_count_blocks) * BIN_THREADS + (int)threadIdx.x;
         // the hint bank of this call's VIEW (sc_common.h); the slot goes to the rasterizer in the list's last word
-        const int slot = view_slot ? sc_clamp_view_slot(*view_slot) : 0;
+        __shared__ int s_view_slot;
+        if (threadIdx.x == 0)
+            s_view_slot = (viewmats && view_registry)
+                              ? view_slot_lookup(viewmats, view_registry, (int)blockIdx.x == n_count_blocks) : 0;
+        __syncthreads();
+        const int slot = s_view_slot;
         tile_work += (size_t)slot * n;
         if (i == 0) *slot_word = slot;
         unsigned own = 0, w = 0;
@@ -290,44 +335,13 @@ __device__ __forceinline__ void publish_meta(const int64_t* __restrict__ meta_de
     __hip_atomic_store(&mirror[4], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // the plain dispatch list (every tile whole, in tile order; no second list) for a frame without Gaussians
-__global__ void plain_order_kernel(int32_t* out, int n_tiles, int n_total, const int32_t* __restrict__ view_slot) {
+__global__ void plain_order_kernel(int32_t* out, int n_tiles, int n_total) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_total) return;
-    if (i == n_total - 1) out[i] = view_slot ? sc_clamp_view_slot(*view_slot) : 0;     // the call's view slot
-    else out[i] = i < n_tiles ? i << 2 : (i == n_total - 2 ? 0 : -1);                  // n_total - 2: "no second list"
+    // n_total - 2: "no second list"; n_total - 1: the view slot (nothing is rasterized: slot 0)
+    out[i] = i < n_tiles ? i << 2 : (i >= n_total - 2 ? 0 : -1);
 }
 
-// ---- view slots (sc_common.h) ----------------------------------------------------------------------------------
-// One thread: camera 0's forward axis (third row of the world -> camera rotation) against the registry's slots.
-// A slot within ~7 degrees is this view's (and follows it: a turning camera keeps its slot); otherwise the least
-// recently used slot is taken over -- its hints are another view's, valid and only less useful, for one frame.
-// Two streams may pick at the same time: every word is written whole, a mixed-up entry only costs a re-pick.
-__global__ void view_slot_kernel(const float* __restrict__ viewmats, unsigned* registry, int32_t* __restrict__ slot_out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float fx = viewmats[8], fy = viewmats[9], fz = viewmats[10];
-    const float inv = rsqrtf(fmaxf(fx * fx + fy * fy + fz * fz, 1e-20f));
-    fx *= inv; fy *= inv; fz *= inv;
-    const unsigned stamp = atomicAdd(&registry[0], 1u) + 1u;
-    int best = -1, lru = 0;
-    float best_dot = 0.9925f;                      // cos(7 degrees)
-    unsigned lru_age = 0;
-    for (int k = 0; k < SC_VIEW_SLOTS; ++k) {
-        const unsigned* e = registry + 4 + 4 * k;
-        const float ex = __uint_as_float(e[0]), ey = __uint_as_float(e[1]), ez = __uint_as_float(e[2]);
-        const bool used = (e[0] | e[1] | e[2]) != 0u;
-        const float d = ex * fx + ey * fy + ez * fz;
-        if (used && d > best_dot) { best_dot = d; best = k; }
-        const unsigned age = used ? stamp - e[3] : 0xffffffffu;
-        if (age > lru_age) { lru_age = age; lru = k; }
-    }
-    if (best < 0) best = lru;
-    unsigned* e = registry + 4 + 4 * best;
-    atomicExch(&e[0], __float_as_uint(fx) | (fx == 0.f && fy == 0.f && fz == 0.f ? 1u : 0u));
-    atomicExch(&e[1], __float_as_uint(fy));
-    atomicExch(&e[2], __float_as_uint(fz));
-    atomicExch(&e[3], stamp);
-    *slot_out = best;
-}
 __global__ void publish_meta_kernel(const int64_t* __restrict__ meta_dev, int64_t* mirror, int64_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_meta(meta_dev, mirror, seq);
 }
@@ -1387,19 +1401,13 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
 extern "C" int sc_view_slots(void) { return SC_VIEW_SLOTS; }
 extern "C" int sc_view_registry_words(void) { return SC_VIEW_REGISTRY_WORDS; }
 
-extern "C" int sc_view_slot_pick(const float* viewmats, int C, int32_t* registry, int32_t* slot_out, sc_stream_t stream) {
-    if (C <= 0 || !viewmats || !registry || !slot_out) return SC_EINVAL;
-    hipLaunchKernelGGL(view_slot_kernel, dim3(1), dim3(64), 0, sc_s(stream), viewmats, (unsigned*)registry, slot_out);
-    SC_LAUNCH_CHECK();
-    return SC_OK;
-}
-
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                                   int tile_size,
                                   int tile_width, int tile_height, int32_t* tiles_per_gauss,
                                   int32_t* isect_offsets, int64_t* meta_dev, int64_t* meta_mirror,
                                   int64_t seq, void* count_workspace, size_t ws_bytes, const int32_t* tile_work,
-                                  const int32_t* view_slot, int32_t* tile_order, sc_stream_t stream) {
+                                  const float* viewmats, int32_t* view_registry, int32_t* tile_order,
+                                  sc_stream_t stream) {
     if (C < 0 || N < 0 || tile_size <= 0 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (!meta_dev) return SC_EINVAL;
     const int64_t CN = (int64_t)C * N;
@@ -1416,7 +1424,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
         if (tile_order && nb64 > 0) {         // nothing to rasterize, but the list must still name every tile
             const int n_total = sc_tile_order_len((int)nb64);
             hipLaunchKernelGGL(plain_order_kernel, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, s, tile_order,
-                               (int)nb64, n_total, view_slot);
+                               (int)nb64, n_total);
             SC_LAUNCH_CHECK();
         }
         return SC_OK;
@@ -1450,11 +1458,11 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
         hipLaunchKernelGGL(bin_count_kernel<true>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
                            count_lds_bytes(L), s, means2d, radii, CN,
                            L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist, n_count_blocks, tile_work,
-                           whint, wstat, g_sc_raster_hint_blend, view_slot, slot_word);
+                           whint, wstat, g_sc_raster_hint_blend, viewmats, (unsigned*)view_registry, slot_word);
     else
         hipLaunchKernelGGL(bin_count_kernel<false>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
                            0, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist,
-                           n_count_blocks, tile_work, whint, wstat, g_sc_raster_hint_blend, view_slot, slot_word);
+                           n_count_blocks, tile_work, whint, wstat, g_sc_raster_hint_blend, viewmats, (unsigned*)view_registry, slot_word);
     SC_LAUNCH_CHECK();
     // tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3]: two extra
     // blocks of the centre-scatter launch (see the kernel)

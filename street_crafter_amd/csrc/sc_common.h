@@ -26,9 +26,10 @@
 extern int g_sc_debug[4];
 extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
 // VIEW SLOTS: the rasterizer's work hint is kept per VIEW (a street rig renders front / front-left / front-right in
-// turn: a frame must not find the hint another camera left).  sc_view_slot_pick (isect_bin.hip) matches camera 0's
-// forward axis against a small device-side registry and hands the call a slot number; the hint buffer is
-// SC_VIEW_SLOTS banks of C * T words, and the slot travels to the rasterizer in the last word of the dispatch list.
+// turn: a frame must not find the hint another camera left).  The count launch (view_slot_lookup, isect_bin.hip)
+// matches camera 0's forward axis against a small device-side registry and gives the call a slot number; the hint
+// buffer is SC_VIEW_SLOTS banks of C * T words, and the slot travels to the rasterizer in the last word of the
+// dispatch list.
 constexpr int SC_VIEW_SLOTS = 8;
 constexpr int SC_VIEW_REGISTRY_WORDS = 4 + 4 * SC_VIEW_SLOTS;   // [0] call counter; per slot: forward axis (3 floats), stamp
 __host__ __device__ static inline int sc_clamp_view_slot(int v) { return v < 0 ? 0 : (v >= SC_VIEW_SLOTS ? SC_VIEW_SLOTS - 1 : v); }

@@ -180,10 +180,8 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
     assert Ks.shape == (C, 3, 3), Ks.shape
     out = _call(_Projection, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
                             far_plane, radius_clip, calc_compensations)
-    if N:
-        slot = _pick_view_slot(viewmats, _stream(means))
-        if slot is not None:
-            out[1]._sc_view_slot = slot          # means2d carries the call's view slot to isect_tiles
+    if N and C:
+        out[1]._sc_viewmats = viewmats           # means2d carries the cameras to isect_tiles (view slots)
     if calc_compensations:
         return out
     return (*out, None)
@@ -201,7 +199,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     if packed:
         raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
     lib = _lib.load()
-    view_slot = getattr(means2d, "_sc_view_slot", None)
+    view_cams = getattr(means2d, "_sc_viewmats", None)
     means2d = _req(means2d.detach(), "means2d")
     radii = _req(radii, "radii", torch.int32)
     depths = _req(depths.detach(), "depths")
@@ -217,7 +215,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     mode = _ISECT_MODE["mode"] if sort else "radix"
     if mode == "bin":
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, total_dev, st, view_slot=view_slot)
+                               tiles_per_gauss, total_dev, st, viewmats=view_cams)
         if res is not None:
             return res[:3]
     wsb = lib.sc_isect_workspace_bytes(C * N)
@@ -281,20 +279,15 @@ def set_view_slots(enabled: bool) -> bool:
     return prev
 
 
-def _pick_view_slot(viewmats: Tensor, st) -> Optional[Tensor]:
-    """int32[1] on the device: the view slot of camera 0 (sc_view_slot_pick: matched on the device against a small
-    registry of forward axes, no host round trip), or None when the dispatch list / the slots are off.  The
-    projection wrappers attach it to `means2d`, which carries it to isect_tiles."""
-    if not (_VIEW_SLOTS["on"] and _TILE_ORDER["on"]) or viewmats.shape[0] == 0:
+def _view_registry(dev) -> Optional[Tensor]:
+    """The device-side table forward axis -> view slot of `dev` (sc_isect_bin_count looks the frame's camera up in
+    it, no host round trip), or None when the dispatch list / the slots are off."""
+    if not (_VIEW_SLOTS["on"] and _TILE_ORDER["on"]):
         return None
-    lib = _lib.load()
-    dev = viewmats.device
     reg = _VIEW_REGISTRY.get(dev.index)
     if reg is None:
-        reg = _VIEW_REGISTRY[dev.index] = torch.zeros(lib.sc_view_registry_words(), dtype=torch.int32, device=dev)
-    slot = torch.empty(1, dtype=torch.int32, device=dev)
-    _lib.check(lib.sc_view_slot_pick(_p(viewmats), int(viewmats.shape[0]), _p(reg), _p(slot), st), "sc_view_slot_pick")
-    return slot
+        reg = _VIEW_REGISTRY[dev.index] = torch.zeros(_lib.load().sc_view_registry_words(), dtype=torch.int32, device=dev)
+    return reg
 
 
 def _tile_work(dev, C, N, tile_width, tile_height) -> Tensor:
@@ -335,7 +328,7 @@ def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                     tiles_per_gauss, total_dev, st, want_ids=True, view_slot=None):
+                     tiles_per_gauss, total_dev, st, want_ids=True, viewmats=None):
     """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
     the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
     rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
@@ -364,11 +357,16 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     if _TILE_ORDER["on"] and int(tile_size) == 16:
         sched = (torch.empty(lib.sc_tile_order_len(C * tile_width * tile_height), dtype=torch.int32, device=dev),
                  _tile_work(dev, C, N, tile_width, tile_height))
+    registry = None
+    if (sched is not None and viewmats is not None and viewmats.device == dev and viewmats.dtype == torch.float32
+            and viewmats.is_contiguous() and viewmats.shape == (C, 4, 4)):
+        registry = _view_registry(dev)
+    if registry is None:
+        viewmats = None
     rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
                                 int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
                                 meta_host.data_ptr(), seq, _p(ws0), ws0.numel(),
-                                None if sched is None else _p(sched[1]),
-                                None if (sched is None or view_slot is None or view_slot.device != dev) else _p(view_slot),
+                                None if sched is None else _p(sched[1]), _p(viewmats), _p(registry),
                                 None if sched is None else _p(sched[0]), st)
     if sched is not None:
         offsets._sc_sched = sched          # travels with isect_offsets to rasterize_to_pixels
@@ -727,14 +725,13 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                                         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                         int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
                                         _p(opac), _p(cols), st), "sc_projection_sh_fwd")
-    view_slot = _pick_view_slot(viewmats, st) if N else None
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     res = None
     if _ISECT_MODE["mode"] == "bin":
         tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, None, st, want_ids=False, view_slot=view_slot)
+                               tiles_per_gauss, None, st, want_ids=False, viewmats=viewmats)
     if res is not None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = res
     else:

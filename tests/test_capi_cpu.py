@@ -76,8 +76,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_rasterize_fwd_ed(None, None, None, None, None, None, 1, 4, 3, 64, 64, 16, 4, 4,
                                    None, None, 0, None, None, None, None, None, 0, None) in (-1, -3)   # needs D == 4
     assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None, None,
-                                  None, None) == -1
-    assert lib.sc_view_slot_pick(None, 1, None, None, None) == -1
+                                  None, None, None) == -1
     assert lib.sc_view_slots() == 8 and lib.sc_view_registry_words() == 4 + 4 * 8
     assert lib.sc_knn3_mean_dist2(None, 0, None, None, 0, None) == 0
     assert lib.sc_knn_workspace_bytes(1000) >= 1000 * 36

@@ -1239,7 +1239,7 @@ def test_tile_dispatch_list_survives_any_hint_values(ops, fill):
 
 def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
     """A rig's cameras are rendered in turn: each must find the hint ITS last frame left, not the previous call's.
-    sc_view_slot_pick files a call under a slot by camera 0's forward axis, on the device; the slot selects the bank
+    The count launch files a call under a slot by camera 0's forward axis, on the device; the slot selects the bank
     of the hint buffer that isect_tiles reads and the rasterizer writes.  Checked: three cameras get three slots and
     keep them, a bank only changes when its own camera renders, the image never depends on any of it, a camera that
     turns slowly keeps its slot, and a ninth view takes over the least recently used slot."""
@@ -1291,24 +1291,24 @@ def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
         _, slot, _ = frame(make_camera(w, h, 600.0, 600.0, yaw=1.2 + 0.05 * k).to(DEV))
         s0 = slot if s0 is None else s0
         assert slot == s0 and slot not in slots.values()
-    # the registry itself: 8 far-apart views fill the slots, the ninth takes over the least recently used one
-    reg = torch.zeros(lib.sc_view_registry_words(), dtype=torch.int32, device=DEV)
-    out = torch.empty(1, dtype=torch.int32, device=DEV)
+    # the registry: 8 far-apart views fill the slots (tiny frames: only the slot matters here), views within the
+    # window reuse theirs, and a ninth view takes over the least recently used slot and no other
+    rendering._VIEW_REGISTRY.pop(dev.index, None)
+    small = make_scene(500, seed=3).to(DEV)
 
-    def pick(yaw, pitch=0.0):
-        V = torch.eye(4)
-        V[2, :3] = torch.tensor([math.sin(yaw) * math.cos(pitch), math.sin(pitch), math.cos(yaw) * math.cos(pitch)])
-        Vd = V[None].to(DEV).contiguous()
-        assert lib.sc_view_slot_pick(Vd.data_ptr(), 1, reg.data_ptr(), out.data_ptr(), None) == 0
+    def pick(yaw):
+        cam = make_camera(64, 48, 60.0, 60.0, yaw=yaw).to(DEV)
+        with torch.no_grad():
+            o = render_gaussians(small, cam, return_intermediates=True)
         torch.cuda.synchronize()
-        return int(out.item())
+        return int(_np(o["_isect_offsets"]._sc_sched[0])[-1])
 
     first = [pick(0.7 * k) for k in range(K_SLOTS)]
     assert sorted(first) == list(range(K_SLOTS))
     assert [pick(0.7 * k + 0.05) for k in range(K_SLOTS)] == first          # within the window: same slots
     assert pick(0.7 * 1 + 0.05) == first[1]
-    assert pick(0.2, pitch=1.2) == first[0]                                  # new view: slot of the LRU view (k = 0)
-    assert pick(0.7 * 2 + 0.05) == first[2]                                  # the others are untouched
+    assert pick(0.7 * K_SLOTS + 0.3) == first[0]                            # new view: the LRU view's slot (k = 0)
+    assert [pick(0.7 * k + 0.05) for k in range(1, K_SLOTS)] == first[1:]   # the others are untouched
 
 
 def test_frame_without_gaussians_is_rendered_everywhere(ops):

@@ -1,7 +1,7 @@
 """The rasterizer's work hint when consecutive calls come from DIFFERENT cameras (a street rig: front / front-left /
 front-right rendered in turn for every time step): the hint a frame finds is the previous call's, i.e. another view's.
 Rasterizer p50 per pattern: plain dispatch, the dispatch list with ONE hint buffer for all views (round 2's first form),
-and with the hint kept per view slot (sc_view_slot_pick).
+and with the hint kept per view slot.
 Usage: python tools/exp_camera_rig.py [frames]"""
 import os
 import sys
