@@ -9,6 +9,7 @@ There is no CPU path: non-HIP tensors raise.
 """
 from __future__ import annotations
 
+import collections
 import math
 import threading
 import time
@@ -257,6 +258,8 @@ def _check_isect_count(n_isects, C, N, tile_width, tile_height):
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
 _BIN_PREDICTION = {}
+_BIN_HISTORY = {}      # same key -> the sizes of the last 8 calls (the prediction covers the largest of them)
+_BIN_HISTORY_LEN = 8   # (tools/exp_camera_rig.py sets 1 for its A/B: round 2's first form)
 _TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [view slots, C * tiles]: the list entries every tile
                        # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
 _TILE_ORDER = {"on": True}
@@ -420,9 +423,17 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             return None
         _lib.check(rc, "sc_isect_bin_sort")
     _BIN_LAST_META[key] = (n_isects, n_records, max_super)
-    # next call: 12.5 % head-room over what this frame needed
-    _BIN_PREDICTION[key] = (n_isects + n_isects // 8 + 4096, n_records + n_records // 8 + 4096,
-                            max_super + max_super // 8 + 64)
+    # next call: 12.5 % head-room over the largest of the last 8 calls of this shape (a rig's cameras are rendered
+    # in turn and see different amounts of the scene: sized by the previous call alone, every switch to a fuller view
+    # missed the prediction and paid the host round trip + a second launch)
+    hist = _BIN_HISTORY.get(key)
+    if hist is None:
+        hist = _BIN_HISTORY[key] = collections.deque(maxlen=_BIN_HISTORY_LEN)
+        while len(_BIN_HISTORY) > 64:
+            _BIN_HISTORY.pop(next(iter(_BIN_HISTORY)))
+    hist.append((n_isects, n_records, max_super))
+    mi, mr, ms = (max(h[j] for h in hist) for j in range(3))
+    _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
     flatten_ids = fids[:n_isects]
     isect_ids = None
     if want_ids:

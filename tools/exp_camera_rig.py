@@ -44,6 +44,26 @@ def run(sc, cams):
     return t[len(t) // 2] * 1e3, t[-1] * 1e3
 
 
+def frames_per_s(sc, cams, hist_len):
+    """whole frames (one stream), and how often the speculative sort launch had been sized too small"""
+    import time
+    rendering._BIN_HISTORY.clear()
+    rendering._BIN_HISTORY_LEN = hist_len
+    with torch.no_grad():
+        for c in cams[:6]:
+            render_gaussians(sc, c)
+        torch.cuda.synchronize()
+        s0 = dict(rendering._BIN_STATS)
+        t0 = time.perf_counter()
+        for c in cams[6:]:
+            render_gaussians(sc, c)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    rendering._BIN_HISTORY_LEN = 8
+    rendering._BIN_HISTORY.clear()
+    return (len(cams) - 6) / dt, rendering._BIN_STATS["exact_relaunch"] - s0["exact_relaunch"]
+
+
 for name, sc in scenes.items():
     print("==", name)
     for label, cams in patterns.items():
@@ -56,3 +76,7 @@ for name, sc in scenes.items():
         on, worst = run(sc, cams)
         print(f"  {label:46s} raster p50 us: plain dispatch {off:6.1f} | list, one hint for all views {shared:6.1f} | "
               f"list, hint per view slot {on:6.1f} (max {worst:6.1f})", flush=True)
+        f1, r1 = frames_per_s(sc, cams, 1)
+        f8, r8 = frames_per_s(sc, cams, 8)
+        print(f"  {'':46s} frames/s, sort sized by the previous call: {f1:7.1f} ({r1} of {len(cams) - 6} relaunched) | by the "
+              f"largest of the last 8 calls: {f8:7.1f} ({r8} relaunched)", flush=True)
