@@ -1311,6 +1311,33 @@ def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
     assert [pick(0.7 * k + 0.05) for k in range(1, K_SLOTS)] == first[1:]   # the others are untouched
 
 
+def test_speculative_sort_is_sized_for_the_fullest_of_the_recent_views(ops):
+    """Two cameras of one rig in turn, one of which sees several times more of the scene: the scatter + sort launch
+    that is enqueued before the counts are known must be sized for the fuller view after it has been seen once
+    (sized by the previous call alone it missed on every switch back to it); the frames do not change."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.pipeline import render_gaussians
+    w, h, n = 640, 400, 40_000
+    sc = make_scene(n, seed=17, z_range=(1.0, 30.0)).to(DEV)
+    cams = [make_camera(w, h, 500.0, 500.0, yaw=0.0).to(DEV), make_camera(w, h, 500.0, 500.0, yaw=0.75).to(DEV)]
+    key = (torch.cuda.current_device(), 1, n, 16, w // 16, h // 16)
+    for d in (rendering._BIN_PREDICTION, rendering._BIN_HISTORY, rendering._BIN_LAST_META):
+        d.pop(key, None)
+    sizes, frames = [], []
+    with torch.no_grad():
+        for f in range(8):
+            if f == 4:
+                before = dict(rendering._BIN_STATS)
+            o = render_gaussians(sc, cams[f % 2], return_intermediates=True)
+            sizes.append(int(o["_flatten_ids"].numel()))
+            frames.append(_np(o["_render_colors"]))
+    assert sizes[0] > 2 * sizes[1] > 0 and sizes[:2] * 3 == sizes[2:]
+    assert rendering._BIN_STATS["exact_relaunch"] == before["exact_relaunch"]
+    assert rendering._BIN_STATS["speculative_ok"] == before["speculative_ok"] + 4
+    for f in range(2, 8):
+        np.testing.assert_array_equal(frames[f].view(np.uint32), frames[f - 2].view(np.uint32))
+
+
 def test_frame_without_gaussians_is_rendered_everywhere(ops):
     """N = 0: the intersection stage's short path still hands the rasterizer a dispatch list that names every tile
     (in the list's item format), so the whole frame is written: background colour, alpha 0 -- with the list on, and
