@@ -1,0 +1,53 @@
+"""How much of isect_tiles' time is the Gaussians' ORDER in memory?  The count and centre passes keep per-workgroup
+grids in LDS and flush them with atomics; with the scene in random order every workgroup touches every cell.  Same
+scene, same frames, Gaussians stored (a) as generated (random), (b) sorted by the 32 x 32 px super-tile of their
+centre under the first camera (what a permutation taken from the previous frame would give).
+Usage: python tools/exp_scene_order.py [frames]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from gsplat.rendering import fully_fused_projection  # noqa: E402
+from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from street_crafter_amd.scenes import Scene, make_scene, make_street_scene  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+dev = "cuda"
+W, H = 1920, 1280
+cams = [bench.frame_camera(s, W, H).to(dev) for s in range(frames + 6)]
+
+
+def permuted(sc, perm):
+    return Scene(sc.means[perm].contiguous(), sc.quats[perm].contiguous(), sc.scales[perm].contiguous(),
+                 sc.opacities[perm].contiguous(), sc.sh[perm].contiguous(), sc.sh_degree)
+
+
+def run(sc):
+    ev = {}
+    with torch.no_grad():
+        for f, c in enumerate(cams):
+            render_gaussians(sc, c, stage_events=ev if f >= 6 else None)
+    torch.cuda.synchronize()
+    out = {}
+    for k, v in ev.items():
+        t = sorted(a.elapsed_time(b) for a, b in v)
+        out[k] = t[len(t) // 2] * 1e3
+    return out
+
+
+for name, sc in (("S-1M", make_scene(1_000_000).to(dev)), ("street-1M", make_street_scene(1_000_000)[0].to(dev))):
+    with torch.no_grad():
+        radii, m2, depths, _, _ = fully_fused_projection(sc.means, None, sc.quats, sc.scales, cams[0].viewmat[None],
+                                                         cams[0].K[None], W, H, near_plane=cams[0].znear, far_plane=cams[0].zfar)
+    sx = (m2[0, :, 0] / 32).floor().clamp(-1, W // 32 + 1).long() + 1
+    sy = (m2[0, :, 1] / 32).floor().clamp(-1, H // 32 + 1).long() + 1
+    key = torch.where(radii[0] > 0, sy * 4096 + sx, torch.full_like(sx, 1 << 40))
+    perm = torch.argsort(key, stable=True)
+    rows = {"as generated (random order)": sc, "sorted by super-tile of the first frame": permuted(sc, perm)}
+    print("==", name)
+    for label, s in rows.items():
+        t = run(s)
+        print(f"  {label:42s} " + " | ".join(f"{k} {v:6.1f}" for k, v in t.items()), flush=True)
