@@ -1507,7 +1507,10 @@ def test_two_host_threads_render_on_one_device(ops):
     from street_crafter_amd.dist import to_uint8_frame
     from street_crafter_amd.pipeline import render_gaussians
     scenes = [make_scene(50_000, seed=31).to(DEV), make_scene(80_000, seed=32, z_range=(1.0, 40.0)).to(DEV)]
-    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.03 * i, shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(8)]
+    # (cameras 0.03 rad apart at first, then 0.3: the second half lands in different VIEW SLOTS, so the two threads'
+    # count launches look up, take over and update the device-side view registry at the same time)
+    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.03 * i if i < 4 else 0.3 * (i - 3) * (-1) ** i,
+                        shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(8)]
 
     def frame(w, f):
         with torch.no_grad():
