@@ -13,7 +13,7 @@ from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 scene = make_scene(300_000).to("cuda")
-cams = [make_camera(1280, 720, 1400.0, 1400.0, yaw=0.01 * i).to("cuda") for i in range(4)]
+cams = [make_camera(1280, 720, 1400.0, 1400.0, yaw=0.25 * i).to("cuda") for i in range(4)]      # four view slots
 op1 = scene.opacities[:, 0].contiguous()
 ref = {}
 peak = []
