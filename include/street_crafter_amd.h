@@ -249,7 +249,23 @@ int sc_projection_sh_fwd(const float* means, const float* quats, const float* sc
                          int sh_degree, int width, int height, float eps2d, float near_plane,
                          float far_plane, float radius_clip, int antialiased, int32_t* radii,
                          float* means2d, float* depths, float* conics, float* opacities_out,
-                         float* colors4, sc_stream_t stream);
+                         float* colors4,
+                         float* records /* nullable: [C,N,12], 16-B aligned: everything the rasterizer gathers per
+                             splat in one 48-B record (x, y, conic a, b | conic c, opacity, colour 0, 1 | colour 2,
+                             3, -, -) for sc_rasterize_fwd_packed.  With records, conics / opacities_out / colors4
+                             may each be NULL (sc_records_unpack rebuilds them on demand) */,
+                         sc_stream_t stream);
+/* sc_rasterize_fwd (4 channels, tile 16, no last_ids) reading `records` instead of the four parameter arrays: one
+ * gather line per splat instead of four.  depth_normalise != 0: the epilogue of
+ * sc_rasterize_fwd_ed.  Bit-identical output.  SC_EUNSUPPORTED when the reference-shaped raster kernel is selected. */
+int sc_rasterize_fwd_packed(const float* records, const float* backgrounds, const uint8_t* tile_masks,
+                            int C, int N, int width, int height, int tile_width, int tile_height,
+                            const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
+                            float* render_colors, float* render_alphas, const int32_t* tile_order,
+                            int32_t* tile_work, int depth_normalise, sc_stream_t stream);
+/* conics [CN,3] / opacities [CN] / colors4 [CN,4] (each nullable) out of CN records */
+int sc_records_unpack(const float* records, int64_t CN, float* conics, float* opacities, float* colors4,
+                      sc_stream_t stream);
 int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,
                         const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
                         int C, int N, int D, int width, int height, int tile_size, int tile_width,

@@ -67,7 +67,10 @@ SIGNATURES = {
     "sc_projection_sh_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_int, c_i32p, c_f32p, c_f32p,
-                                       c_f32p, c_f32p, c_f32p, c_stream]),
+                                       c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "sc_rasterize_fwd_packed": (C.c_int, [c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          c_i32p, c_i32p, C.c_int64, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int, c_stream]),
+    "sc_records_unpack": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
     "sc_rasterize_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sc_tile_order_len": (C.c_int, [C.c_int]),
     "sc_rasterize_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,

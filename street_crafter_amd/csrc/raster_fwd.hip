@@ -138,7 +138,9 @@ __global__ void raster_fwd_ref_kernel(
 // TRACK: record last_ids (the sorted index of the last splat each pixel blended), needed only by
 // the backward pass; inference launches the variant without it.
 // NSUB: 1 = whole tile, 2 = half (8 rows), 4 = quarter (4 rows); `sub` = which one.
-template <int CDIM, bool TRACK, int NSUB>
+// PACKED: `means2d` points to one 48-B record per Gaussian, (x, y, conic a, b | conic c, opacity, colour 0, 1 |
+// colour 2, 3, -, -), written by projection_sh_fwd_kernel for the fused forward: one gather line per splat instead of four.
+template <int CDIM, bool TRACK, int NSUB, bool PACKED = false>
 __device__ __forceinline__ void raster_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -235,6 +237,15 @@ __device__ __forceinline__ void raster_item(
     bool p_live[SB];
     int g_next[SB];
     auto load_splat = [&](int g, int j) {
+        if (PACKED) {
+            const float4* rec = reinterpret_cast<const float4*>(means2d) + (int64_t)g * 3;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+            p_xy[j] = make_float2(q0.x, q0.y);
+            p_a[j] = q0.z; p_b[j] = q0.w; p_c[j] = q1.x;
+            p_op[j] = q1.y;
+            p_col[j] = make_float4(q1.z, q1.w, q2.x, CDIM > 3 ? q2.y : 0.f);
+            return;
+        }
         p_xy[j] = *reinterpret_cast<const float2*>(means2d + (int64_t)g * 2);
         const float* cn = conics + (int64_t)g * 3;
         p_a[j] = cn[0]; p_b[j] = cn[1]; p_c[j] = cn[2];
@@ -378,7 +389,7 @@ __device__ __forceinline__ void raster_item(
     if (tile_work && lane == 0) tile_work[tflat] = walked;     // halves: the later finisher's count stands
 }
 
-template <int CDIM, bool TRACK>
+template <int CDIM, bool TRACK, bool PACKED = false>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -422,11 +433,11 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
         }
     }
     if (kind == 0)
-        raster_item<CDIM, TRACK, 1>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 1, PACKED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
                                     render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s, tile_work);
     else
-        raster_item<CDIM, TRACK, 2>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 2, PACKED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
                                     render_colors, render_alphas, last_ids, dbg, tflat, kind - 1, xyoa_s, bck_s, col_s,
                                     tile_work);
@@ -468,7 +479,8 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     if ((int64_t)tile_width * tile_size < width || (int64_t)tile_height * tile_size < height) return SC_EINVAL;
     if (C == 0) return SC_OK;
     if (!isect_offsets || !render_colors || !render_alphas) return SC_EINVAL;   // last_ids is nullable
-    if (n_isects > 0 && (!means2d || !conics || !colors || !opacities || !flatten_ids)) return SC_EINVAL;
+    const bool packed = (epilogue & 2) != 0;      // means2d = 48-B records (raster_item<.., PACKED>)
+    if (n_isects > 0 && (!means2d || !flatten_ids || (!packed && (!conics || !colors || !opacities)))) return SC_EINVAL;
     if (C > 65535 || tile_height > 65535) return SC_EINVAL;
     dim3 grid(tile_width, tile_height, C);
     if ((int64_t)C * N > 0x7fffffffLL) return SC_EINVAL;
@@ -476,7 +488,8 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     const int variant = g_sc_raster_fwd_variant;
     // the depth-normalising epilogue exists in the wave-per-tile kernel with 4 channels only
     if (epilogue && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
-    const int kdbg = g_sc_debug[1] | (epilogue ? 0x100 : 0);
+    if (packed && last_ids) return SC_EUNSUPPORTED;
+    const int kdbg = g_sc_debug[1] | ((epilogue & 1) ? 0x100 : 0);
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
@@ -486,7 +499,12 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
                        render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work)
-        if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
+        if (packed)
+            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, false, true>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d,
+                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
+                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,
+                               render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work);
+        else if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
         else { if (last_ids) SC_LAUNCH_WAVE(3, true); else SC_LAUNCH_WAVE(3, false); }
 #undef SC_LAUNCH_WAVE
         SC_LAUNCH_CHECK();
@@ -537,4 +555,21 @@ extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, co
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
                               render_colors, render_alphas, nullptr, tile_order, tile_work, workspace, ws_bytes, stream, 1);
+}
+
+
+// The fused forward's rasterizer: `records` = one 48-B record per (camera, Gaussian) as sc_projection_sh_fwd writes
+// them (x, y, conic a, b | conic c, opacity, colour 0, 1 | colour 2, 3, -, -); 4 channels, tile 16, the wave kernel.
+// depth_normalise != 0: the 4th channel is divided by max(alpha, 1e-10) as in sc_rasterize_fwd_ed.
+extern "C" int sc_rasterize_fwd_packed(const float* records, const float* backgrounds, const uint8_t* tile_masks,
+                                       int C, int N, int width, int height, int tile_width, int tile_height,
+                                       const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
+                                       float* render_colors, float* render_alphas, const int32_t* tile_order,
+                                       int32_t* tile_work, int depth_normalise, sc_stream_t stream) {
+    if (g_sc_raster_fwd_variant < 3) return SC_EUNSUPPORTED;
+    if (records && ((uintptr_t)records & 15)) return SC_EINVAL;
+    return rasterize_fwd_impl(records, nullptr, nullptr, nullptr, backgrounds, tile_masks, C, N, 4, width, height, 16,
+                              tile_width, tile_height, isect_offsets, flatten_ids, n_isects, render_colors,
+                              render_alphas, nullptr, tile_order, tile_work, nullptr, 0, stream,
+                              2 | (depth_normalise ? 1 : 0));
 }

@@ -265,6 +265,7 @@ _TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 
 _TILE_ORDER = {"on": True}
 _LAZY_ISECT_IDS = {"on": True}
 _VIEW_SLOTS = {"on": True}
+_PACKED_RECORDS = {"on": True}
 _VIEW_REGISTRY = {}    # device index -> int32 [sc_view_registry_words()]: the device-side table forward axis -> view slot
 
 
@@ -272,6 +273,13 @@ def set_tile_order(enabled: bool) -> bool:
     """Longest-running-tile-first dispatch of the rasterizer (A/B switch; results are identical either way).
     Returns the previous setting."""
     prev, _TILE_ORDER["on"] = _TILE_ORDER["on"], bool(enabled)
+    return prev
+
+
+def set_packed_records(enabled: bool) -> bool:
+    """A/B switch of the fused forward's packed rasterizer records (results are identical either way).  Returns the
+    previous setting."""
+    prev, _PACKED_RECORDS["on"] = _PACKED_RECORDS["on"], bool(enabled)
     return prev
 
 
@@ -696,9 +704,39 @@ def _fused_forward_ok(tensors, sh_degree, render_mode, tile_size, colors) -> boo
 
 class _FusedMeta(dict):
     """gsplat's meta dict.  The fused forward does not materialise `isect_ids` (8 B x I of keys nothing on
-    this path reads); `meta["isect_ids"]` builds them on first access from the tensors already here."""
+    this path reads); `meta["isect_ids"]` builds them on first access from the tensors already here.  Likewise
+    `conics` / `opacities` / `colors` when the rasterizer gathered from packed records: first access unpacks them."""
+
+    _FROM_RECORDS = ("conics", "opacities", "colors")
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return (dict.__contains__(self, key) or key == "isect_ids"
+                or (key in self._FROM_RECORDS and dict.__contains__(self, "_records")))
 
     def __missing__(self, key):
+        if key in self._FROM_RECORDS and dict.__contains__(self, "_records"):
+            # the fused frame gathered these from the rasterizer's packed records and never wrote the arrays:
+            # one kernel rebuilds all three on first access, on the current stream
+            rec, (C, N) = dict.__getitem__(self, "_records"), dict.__getitem__(self, "_records_shape")
+            dev = rec.device
+            out = {"conics": torch.empty((C, N, 3), dtype=torch.float32, device=dev),
+                   "opacities": torch.empty((C, N), dtype=torch.float32, device=dev),
+                   "colors": torch.empty((C, N, 4), dtype=torch.float32, device=dev)}
+            cur, producer = torch.cuda.current_stream(dev), dict.__getitem__(self, "_records_stream")
+            if cur != producer:
+                cur.wait_stream(producer)
+            _lib.check(_lib.load().sc_records_unpack(rec.data_ptr(), C * N, out["conics"].data_ptr(),
+                                                     out["opacities"].data_ptr(), out["colors"].data_ptr(),
+                                                     cur.cuda_stream), "sc_records_unpack")
+            for k, v in out.items():
+                self[k] = v
+            return out[key]
         if key != "isect_ids":
             raise KeyError(key)
         with torch.no_grad():
@@ -727,15 +765,23 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     radii = torch.empty((C, N), dtype=torch.int32, device=dev)
     means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
     depths = torch.empty((C, N), dtype=torch.float32, device=dev)
-    conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
-    opac = torch.empty((C, N), dtype=torch.float32, device=dev)
-    cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
     st = _stream(means)
+    # the rasterizer's 48-B record per (camera, Gaussian): one gather line per splat instead of four.  With it the
+    # conics / opacities / colours arrays of `meta` are not written at all (32 B per Gaussian the frame never reads):
+    # _FusedMeta rebuilds them from the records on first access
+    use_records = _PACKED_RECORDS["on"] and int(tile_size) == 16 and N > 0 and C > 0
+    records = conics = opac = cols = None
+    if use_records:
+        records = torch.empty((C, N, 12), dtype=torch.float32, device=dev)
+    else:
+        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+        opac = torch.empty((C, N), dtype=torch.float32, device=dev)
+        cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
     _lib.check(lib.sc_projection_sh_fwd(_p(means), _p(quats), _p(scales), _p(opacities), _p(colors), _p(viewmats),
                                         _p(Ks), _p(centers), C, N, K, int(sh_degree), int(width), int(height),
                                         float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
                                         int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
-                                        _p(opac), _p(cols), st), "sc_projection_sh_fwd")
+                                        _p(opac), _p(cols), _p(records), st), "sc_projection_sh_fwd")
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     res = None
@@ -754,26 +800,42 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                                  torch.zeros(C, 1, device=dev)], dim=-1).contiguous()
     render_colors = torch.empty((C, height, width, 4), dtype=torch.float32, device=dev)
     render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
-    args = (_p(means2d), _p(conics), _p(cols), _p(opac), _p(backgrounds), None, C, N, 4, int(width), int(height),
-            int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-            _p(render_colors), _p(render_alphas))
     order, work = _sched_of(isect_offsets, C * tile_width * tile_height)
     sch = (_p(order), _p(work))
-    if render_mode == "RGB+ED":
-        rc = lib.sc_rasterize_fwd_ed(*args, *sch, None, 0, st)
-        if rc == -3:          # the reference-shaped raster kernel is selected: plain launch + the torch post-step
-            _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
-            render_colors = torch.cat([render_colors[..., :-1],
-                                       render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+    if records is not None:
+        rc = lib.sc_rasterize_fwd_packed(_p(records), _p(backgrounds), None, C, N, int(width), int(height), tile_width,
+                                         tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+                                         _p(render_colors), _p(render_alphas), *sch, int(render_mode == "RGB+ED"), st)
+        if rc == -3:          # the reference-shaped raster kernel is selected: it reads the separate arrays
+            conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+            opac = torch.empty((C, N), dtype=torch.float32, device=dev)
+            cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
+            _lib.check(lib.sc_records_unpack(_p(records), C * N, _p(conics), _p(opac), _p(cols), st), "sc_records_unpack")
+            records = None
         else:
-            _lib.check(rc, "sc_rasterize_fwd_ed")
-    else:
-        _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
-    meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+            _lib.check(rc, "sc_rasterize_fwd_packed")
+    if records is None:
+        args = (_p(means2d), _p(conics), _p(cols), _p(opac), _p(backgrounds), None, C, N, 4, int(width), int(height),
+                int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+                _p(render_colors), _p(render_alphas))
+        if render_mode == "RGB+ED":
+            rc = lib.sc_rasterize_fwd_ed(*args, *sch, None, 0, st)
+            if rc == -3:          # the reference-shaped raster kernel is selected: plain launch + the torch post-step
+                _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
+                render_colors = torch.cat([render_colors[..., :-1],
+                                           render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
+            else:
+                _lib.check(rc, "sc_rasterize_fwd_ed")
+        else:
+            _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
+    meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths,
                        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
                        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
-                       "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "colors": cols,
-                       "fused": True})
+                       "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "fused": True})
+    if records is not None:          # conics / opacities / colors: rebuilt from the records on first access
+        meta.update({"_records": records, "_records_shape": (C, N), "_records_stream": torch.cuda.current_stream(dev)})
+    else:
+        meta.update({"conics": conics, "opacities": opac, "colors": cols})
     if isect_ids is not None:
         meta["isect_ids"] = isect_ids
     return render_colors, render_alphas, meta

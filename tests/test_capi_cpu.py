@@ -68,11 +68,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_camera_centers(None, -1, None, None) == -1
     assert lib.sc_camera_centers(None, 0, None, None) == 0
     assert lib.sc_projection_sh_fwd(None, None, None, None, None, None, None, None, 1, 8, 4, 5, 64, 64, 0.3, 0.01,
-                                    1e10, 0.0, 1, None, None, None, None, None, None, None) == -1     # degree > 4
+                                    1e10, 0.0, 1, None, None, None, None, None, None, None, None) == -1     # degree > 4
     assert lib.sc_projection_sh_fwd(None, None, None, None, None, None, None, None, 1, 8, 3, 1, 64, 64, 0.3, 0.01,
-                                    1e10, 0.0, 1, None, None, None, None, None, None, None) == -1     # K < 4
+                                    1e10, 0.0, 1, None, None, None, None, None, None, None, None) == -1     # K < 4
     assert lib.sc_projection_sh_fwd(None, None, None, None, None, None, None, None, 1, 0, 4, 1, 64, 64, 0.3, 0.01,
-                                    1e10, 0.0, 1, None, None, None, None, None, None, None) == 0      # N == 0
+                                    1e10, 0.0, 1, None, None, None, None, None, None, None, None) == 0      # N == 0
+    assert lib.sc_rasterize_fwd_packed(None, None, None, 1, 4, 64, 64, 4, 4, None, None, 0, None, None, None, None, 1,
+                                       None) == -1
+    assert lib.sc_records_unpack(None, 8, None, None, None, None) == -1 and lib.sc_records_unpack(None, 0, None, None, None, None) == 0
     assert lib.sc_rasterize_fwd_ed(None, None, None, None, None, None, 1, 4, 3, 64, 64, 16, 4, 4,
                                    None, None, 0, None, None, None, None, None, 0, None) in (-1, -3)   # needs D == 4
     assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None, None,

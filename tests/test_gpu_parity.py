@@ -922,6 +922,17 @@ def test_rasterization_fused_matches_composition(ops, render_mode, rasterize_mod
             rendering.set_fused_rasterization(prev)
     (rc_f, ra_f, m_f), (rc_c, ra_c, m_c) = outs
     assert m_f["fused"] and not m_c["fused"]
+    # the fused rasterizer gathered from packed 48-B records: conics / opacities / colors of its meta are rebuilt
+    # from them on first access (compared below), and the frame is the same without the records
+    assert not dict.__contains__(m_f, "conics") and "conics" in m_f and m_f.get("opacities") is not None
+    prev = rendering.set_packed_records(False)
+    try:
+        with torch.no_grad():
+            rc_u, ra_u, m_u = ops.rasterization(sc.means, sc.quats, sc.scales, sc.opacities[:, 0], sc.sh, V, K, 640, 400, **kw)
+    finally:
+        rendering.set_packed_records(prev)
+    assert m_u["fused"] and dict.__contains__(m_u, "conics")
+    assert torch.equal(rc_u, rc_f) and torch.equal(ra_u, ra_f) and torch.equal(m_u["colors"], m_f["colors"])
     assert float(ra_f.sum()) > 0
     np.testing.assert_array_equal(_np(rc_f).view(np.uint32), _np(rc_c).view(np.uint32))
     np.testing.assert_array_equal(_np(ra_f).view(np.uint32), _np(ra_c).view(np.uint32))
