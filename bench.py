@@ -42,7 +42,7 @@ OPERATOR_KERNEL = {
     "isect_tiles": "bin_count + center_scatter + bin_scatter_flat + super_sort (4 kernels)",
     "isect_offset_encode": "(none: cached bucket scan)",
     "spherical_harmonics": "sh_fwd_kernel",
-    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false>",
+    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false, false>",
 }
 
 
