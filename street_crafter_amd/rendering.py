@@ -717,18 +717,18 @@ class _FusedMeta(dict):
 
     def __contains__(self, key):
         return (dict.__contains__(self, key) or key == "isect_ids"
-                or (key in self._FROM_RECORDS and dict.__contains__(self, "_records")))
+                or (key in self._FROM_RECORDS and getattr(self, "_sc_records", None) is not None))
 
     def __missing__(self, key):
-        if key in self._FROM_RECORDS and dict.__contains__(self, "_records"):
+        if key in self._FROM_RECORDS and getattr(self, "_sc_records", None) is not None:
             # the fused frame gathered these from the rasterizer's packed records and never wrote the arrays:
             # one kernel rebuilds all three on first access, on the current stream
-            rec, (C, N) = dict.__getitem__(self, "_records"), dict.__getitem__(self, "_records_shape")
+            rec, (C, N), producer = self._sc_records          # (kept as an attribute: not one of gsplat's keys)
             dev = rec.device
             out = {"conics": torch.empty((C, N, 3), dtype=torch.float32, device=dev),
                    "opacities": torch.empty((C, N), dtype=torch.float32, device=dev),
                    "colors": torch.empty((C, N, 4), dtype=torch.float32, device=dev)}
-            cur, producer = torch.cuda.current_stream(dev), dict.__getitem__(self, "_records_stream")
+            cur = torch.cuda.current_stream(dev)
             if cur != producer:
                 cur.wait_stream(producer)
             _lib.check(_lib.load().sc_records_unpack(rec.data_ptr(), C * N, out["conics"].data_ptr(),
@@ -833,7 +833,7 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,
                        "width": width, "height": height, "tile_size": tile_size, "n_cameras": C, "fused": True})
     if records is not None:          # conics / opacities / colors: rebuilt from the records on first access
-        meta.update({"_records": records, "_records_shape": (C, N), "_records_stream": torch.cuda.current_stream(dev)})
+        meta._sc_records = (records, (C, N), torch.cuda.current_stream(dev))
     else:
         meta.update({"conics": conics, "opacities": opac, "colors": cols})
     if isect_ids is not None:
