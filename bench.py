@@ -42,7 +42,7 @@ OPERATOR_KERNEL = {
     "isect_tiles": "bin_count + center_scatter + bin_scatter_flat + super_sort (4 kernels)",
     "isect_offset_encode": "(none: cached bucket scan)",
     "spherical_harmonics": "sh_fwd_kernel",
-    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false, false>",
+    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false, false, false>",
 }
 
 
@@ -250,7 +250,7 @@ def run_rank(args):
             return None
     else:
         from street_crafter_amd import _lib, rendering
-        from street_crafter_amd.pipeline import algorithmic_bytes, render_gaussians
+        from harness.caller import algorithmic_bytes, render_gaussians
         from street_crafter_amd.scenes import make_scene
         _lib.load()
         if args.isect_mode:
@@ -393,7 +393,7 @@ def run_rank(args):
     secondary = {}
     if world == 1:
         from gsplat.rendering import rasterization
-        from street_crafter_amd.pipeline import render_novel_view_u8
+        from harness.caller import render_novel_view_u8
         op1 = scene.opacities[:, 0].contiguous()
 
         def fresh():

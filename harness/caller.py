@@ -15,7 +15,7 @@ from typing import Dict
 
 import torch
 
-from .scenes import Camera, Scene
+from street_crafter_amd.scenes import Camera, Scene
 
 
 def render_gaussians(scene: Scene, camera: Camera, tile_size: int = 16, use_depth: bool = True,
@@ -130,7 +130,7 @@ def render_novel_view_u8(fg_scene: Scene, sky_scene, camera: Camera, rounding: s
     SURVEY 8f-2) and composite + clamp + uint8 conversion are ONE kernel (sc_frame_composite_u8) instead
     of seven torch elementwise passes over the frame.  -> uint8 [H,W,3]."""
     from gsplat.rendering import rasterization
-    from .dist import to_uint8_frame
+    from street_crafter_amd.dist import to_uint8_frame
 
     def one_pass(sc):
         if not fused:

@@ -200,8 +200,7 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
                          walked: the scheduling hint the NEXT frame of that view has its tile_order built from
                          (persistent, caller-owned, zero-initialised; stale or half-updated values are fine).  Without
                          tile_order: bank 0 */,
-                     void* workspace /* nullable: sc_rasterize_workspace_bytes(C,tile_width,tile_height) bytes */,
-                     size_t ws_bytes, sc_stream_t stream);
+                     sc_stream_t stream);
 /* number of int32 items in the dispatch-list buffer for `total_tiles` tiles: the forward's list (total_tiles +
  * total_tiles / 8 + 8 items: every tile + room for the split ones, padded with -1), then a whole-tile list in the
  * same order (total_tiles items `tile << 2`), one word that says whether that second list was built: it is only
@@ -209,9 +208,6 @@ int sc_rasterize_fwd(const float* means2d, const float* conics, const float* col
  * whole tiles; by default sc_rasterize_bwd follows the forward's list, half tiles included -- and, last, the view
  * slot of the call (see VIEW SLOTS). */
 int sc_tile_order_len(int total_tiles);
-/* scratch the rasterizer wants for this shape (the shipped kernels need none: 256; kept so that a kernel
- * with scratch needs no ABI change) */
-size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height);
 /* Gradient outputs must be ZERO-FILLED by the caller (the kernel accumulates with atomics).
  * v_means2d_abs nullable (absgrad). */
 int sc_rasterize_bwd(const float* means2d, const float* conics, const float* colors,
@@ -271,8 +267,7 @@ int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* 
                         int C, int N, int D, int width, int height, int tile_size, int tile_width,
                         int tile_height, const int32_t* isect_offsets, const int32_t* flatten_ids,
                         int64_t n_isects, float* render_colors, float* render_alphas,
-                        const int32_t* tile_order, int32_t* tile_work, void* workspace,
-                        size_t ws_bytes, sc_stream_t stream);
+                        const int32_t* tile_order, int32_t* tile_work, sc_stream_t stream);
 
 /* ---- frame export for the multi-GPU gather: the tail of render_novel_view
  *      (street_gaussian/models/street_gaussian_renderer.py:151-163: fg + sky * (1 - acc), clamp) and the
@@ -304,9 +299,10 @@ int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_st
  *   key "raster_bwd": 0 = reference-shaped (one lane per pixel), 1 = one wave per tile (default)
  *   key "raster_bwd_split": 1 = the backward follows the forward's dispatch list including its half tiles (default),
  *                     0 = the whole-tile list behind it
- *   key "debug0".."debug3": diagnostic skips used to price parts of a kernel (outputs invalid
- *       when non-zero; 0 in production)
- * Returns the previous value, or SC_EINVAL for an unknown key. */
+ * Returns the previous value, or SC_EINVAL for an unknown key.
+ * (The diagnostic skips "debug0".."debug3" of rounds 1-2 are NOT part of this library any more: they exist only in
+ *  the separate diagnostic build, lib/libstreet_crafter_hip_diag.so (-DSC_DIAG), which tools/exp_*.py load
+ *  explicitly; here they are unknown keys.) */
 int sc_set_option(const char* key, int value);
 
 #ifdef __cplusplus

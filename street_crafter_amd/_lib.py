@@ -11,8 +11,23 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libstreet_crafter_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libstreet_crafter_hip_diag.so")
 
 _lib = None
+_path = LIB_PATH
+
+
+def use_diagnostic_build():
+    """tools/exp_*.py only: load the DIAGNOSTIC build (`python -m street_crafter_amd.build --diag`; same sources
+    with the sc_set_option("debug0".."debug3") skip switches compiled in) instead of the shipped library.  Must be
+    called before the first operator call; nothing in the package, tests/ or bench.py calls it."""
+    global _path
+    if _lib is not None and _path != DIAG_LIB_PATH:
+        raise RuntimeError("use_diagnostic_build() must be called before the library is first loaded")
+    if not os.path.exists(DIAG_LIB_PATH):
+        raise ImportError(f"diagnostic library not built ({DIAG_LIB_PATH} missing): "
+                          "python -m street_crafter_amd.build --diag")
+    _path = DIAG_LIB_PATH
 
 c_f32p = C.c_void_p   # device pointers travel as integers
 c_i32p = C.c_void_p
@@ -59,10 +74,10 @@ SIGNATURES = {
                             c_stream]),
     "sc_rasterize_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
-                                   c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+                                   c_f32p, c_f32p, c_i32p, c_i32p, c_i32p, c_stream]),
     "sc_rasterize_fwd_ed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
-                                      c_f32p, c_f32p, c_i32p, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
+                                      c_f32p, c_f32p, c_i32p, c_i32p, c_stream]),
     "sc_camera_centers": (C.c_int, [c_f32p, C.c_int, c_f32p, c_stream]),
     "sc_projection_sh_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -71,7 +86,6 @@ SIGNATURES = {
     "sc_rasterize_fwd_packed": (C.c_int, [c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           c_i32p, c_i32p, C.c_int64, c_f32p, c_f32p, c_i32p, c_i32p, C.c_int, c_stream]),
     "sc_records_unpack": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, c_stream]),
-    "sc_rasterize_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sc_tile_order_len": (C.c_int, [C.c_int]),
     "sc_rasterize_bwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
@@ -91,11 +105,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(_path):
         raise ImportError(
-            f"street_crafter_amd: HIP library not built ({LIB_PATH} missing). "
+            f"street_crafter_amd: HIP library not built ({_path} missing). "
             "Build it with `python -m street_crafter_amd.build` (needs hipcc, gfx950).")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(_path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
         fn.restype = res

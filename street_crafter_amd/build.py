@@ -2,9 +2,14 @@
 
     python -m street_crafter_amd.build            # incremental
     python -m street_crafter_amd.build --force
+    python -m street_crafter_amd.build --diag     # the DIAGNOSTIC build as well (tools/exp_*.py only)
 
 Output: street_crafter_amd/lib/libstreet_crafter_hip.so (git-ignored, shipped to the GPU box by
 gpurun).  hipcc cross-compiles without a GPU, so this also is the "does it build" check.
+
+The diagnostic build (lib/libstreet_crafter_hip_diag.so, -DSC_DIAG, objects under build/diag/) is the same
+sources with the `debug0..3` skip switches compiled in (csrc/sc_common.h).  Nothing in the package, the tests
+or bench.py loads it; the measuring tools under tools/ ask for it with _lib.use_diagnostic_build().
 """
 from __future__ import annotations
 
@@ -18,6 +23,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libstreet_crafter_hip.so")
+LIB_DIAG = os.path.join(LIBDIR, "libstreet_crafter_hip_diag.so")
 ARCH = "gfx950"
 
 SOURCES = ["capi.hip", "projection.hip", "isect.hip", "isect_bin.hip", "radix_sort.hip", "sh.hip",
@@ -47,11 +53,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force, verbose):
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+def _compile(src, force, verbose, diag=False):
+    obj = os.path.join(OBJDIR, "diag" if diag else "", src.replace(".hip", ".o"))
     if not force and not _stale(obj, _deps(src)):
         return obj, False
-    cmd = [_hipcc(), *COMMON_FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *COMMON_FLAGS, *(["-DSC_DIAG"] if diag else []), "-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -62,23 +68,27 @@ def _compile(src, force, verbose):
     return obj, True
 
 
-def build(force=False, verbose=False, jobs=None):
+def build(force=False, verbose=False, jobs=None, diag=False):
+    """Builds the shipped library (diag=False) or the diagnostic one (diag=True); returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(os.path.join(OBJDIR, "diag") if diag else OBJDIR, exist_ok=True)
+    lib = LIB_DIAG if diag else LIB
     jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, verbose), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, force, verbose, diag), SOURCES))
     objs = [o for o, _ in results]
-    if force or any(ch for _, ch in results) or _stale(LIB, objs):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if force or any(ch for _, ch in results) or _stale(lib, objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    if "--diag" in sys.argv:
+        print("built", build(force="--force" in sys.argv, verbose=True, diag=True))

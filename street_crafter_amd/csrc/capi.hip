@@ -3,7 +3,11 @@
 #include <string.h>
 #include <time.h>
 
-extern "C" const char* sc_version(void) { return "street_crafter_amd 0.1.0 (gfx950)"; }
+#ifdef SC_DIAG
+extern "C" const char* sc_version(void) { return "street_crafter_amd 0.3.0 (gfx950, DIAGNOSTIC build)"; }
+#else
+extern "C" const char* sc_version(void) { return "street_crafter_amd 0.3.0 (gfx950)"; }
+#endif
 
 extern "C" const char* sc_target_arch(void) { return "gfx950"; }
 
@@ -19,7 +23,9 @@ extern "C" const char* sc_error_string(int code) {
     return "street_crafter_amd: unknown error";
 }
 
-int g_sc_debug[4] = {0, 0, 0, 0};
+#ifdef SC_DIAG
+int g_sc_debug[4] = {0, 0, 0, 0};       // diagnostic build only (sc_common.h)
+#endif
 
 // Host-side wait for the sequence number that center_scatter_kernel publishes behind the frame's sizes
 // (host-mapped pinned memory, include/street_crafter_amd.h sc_isect_bin_count).  A plain spin in C: a Python host
@@ -44,12 +50,14 @@ extern "C" int sc_wait_i64(const int64_t* addr, int64_t value, int64_t timeout_u
 
 extern "C" int sc_set_option(const char* key, int value) {
     if (!key) return SC_EINVAL;
+#ifdef SC_DIAG     // "debug0".."debug3" exist in the diagnostic build only: the shipped library answers SC_EINVAL
     if (strncmp(key, "debug", 5) == 0 && key[5] >= '0' && key[5] <= '3' && key[6] == 0) {
         if (value < 0) return SC_EINVAL;
         const int prev = g_sc_debug[key[5] - '0'];
         g_sc_debug[key[5] - '0'] = value;
         return prev;
     }
+#endif
     if (strcmp(key, "raster_bwd") == 0) {
         if (value < 0 || value > 1) return SC_EINVAL;
         const int prev = g_sc_raster_bwd_variant;

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
     unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq,
     const unsigned* __restrict__ whint, const unsigned* __restrict__ wstat, int32_t* __restrict__ tile_order,
-    int n_tiles_total, int staged, int split_pct, int want_bwd, int odbg) {
+    int n_tiles_total, int staged, int split_pct, int want_bwd SC_DIAG_PARAM(odbg)) {
     extern __shared__ unsigned lds[];
     __shared__ long long wave_tot[16];
     __shared__ unsigned wave_max[16];
@@ -397,8 +397,12 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         const int lane = sc_lane();
         cls[threadIdx.x] = 0;
         if (threadIdx.x == 0) { s_lim = 0; s_nsplit = 0; s_tail = 1024; s_before = 0x7fffffff; }
+#ifdef SC_DIAG      // stage stamps of this one workgroup (tools/exp_order_job.py), diagnostic build only
         __shared__ long long s_stamp[10];
         auto stamp = [&](int k) { if ((odbg & 64) && threadIdx.x == 0) s_stamp[k] = (long long)wall_clock64(); };
+#else
+        auto stamp = [](int) {};
+#endif
         stamp(0);
         const unsigned wmax = whint ? wstat[0] : 0u;
         const long long wsum = whint ? (long long)wstat[1] : 0;
@@ -407,11 +411,11 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         const bool skewed = (long long)wmax * n_tiles_total >= 3 * wsum;
         long long tot;
         stamp(1);
-        if (odbg & 1) return;          // diagnostic (debug1 bit 16): price the start
+        if (SC_DIAG_BIT(odbg, 1)) return;          // diagnostic (debug1 bit 16): price the start
         int shift = 0;
         while ((wmax >> shift) > 1023u) ++shift;
         stamp(2);
-        if (odbg & 2) return;
+        if (SC_DIAG_BIT(odbg, 2)) return;
         // (neighbouring tiles = neighbouring lanes often share a class, and 64 lanes adding to one LDS counter
         // serialise.  A RUN of equal classes among consecutive lanes is added by its first lane alone, in both sweeps.)
         auto run_of = [&](int c, int* head_lane, int* len) {
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         }
         __syncthreads();
         stamp(3);
-        if (odbg & 4) return;          // ... + the class sweep
+        if (SC_DIAG_BIT(odbg, 4)) return;          // ... + the class sweep
         // the forward list is staged in LDS behind the class table (2 B per item) when the launch provides the room
         unsigned short* stage = staged ? snap + tpad : nullptr;
         const unsigned cnt = cls[threadIdx.x];
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         }
         __syncthreads();
         stamp(4);
-        if (odbg & 8) return;          // ... + the class scan and the split decision
+        if (SC_DIAG_BIT(odbg, 8)) return;          // ... + the class scan and the split decision
         for (int i = threadIdx.x; i < n_round; i += BIN_THREADS) {
             const int c = i < n_tiles_total ? (int)snap[i] : -1;
             int hl, len;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         if (threadIdx.x == 0) tile_order[n_items_max + n_tiles_total] = want_bwd;       // "the second list is there"
         const int n_items = n_tiles_total + n_split;
         stamp(5);
-        if (odbg & 16) return;         // ... + the scatter sweep
+        if (SC_DIAG_BIT(odbg, 16)) return;         // ... + the scatter sweep
         if (stage) {
             // (this ONE workgroup's scattered 4-B global stores were what it spent most of its time on -- it had become
             // the last of the launch to finish: center_scatter 24 -> 29 us on S-1M.)  A tile listed as halves sits in
@@ -532,9 +536,11 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
             for (int i = n_items + threadIdx.x; i < n_items_max; i += BIN_THREADS) tile_order[i] = -1;
         }
         stamp(6);
+#ifdef SC_DIAG
         if ((odbg & 64) && threadIdx.x == 0) {          // diagnostic: stage times in 10-ns ticks at the end of the buffer's forward part
             for (int k = 0; k < 7; ++k) tile_order[n_items_max - 8 + k] = (int)(s_stamp[k] - s_stamp[0]);
         }
+#endif
         return;
     }
     const int cblock = (int)blockIdx.x - 3;
@@ -609,7 +615,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     const uint4* __restrict__ sorted, const int64_t* __restrict__ n_visible, Geo g, int n_sbuckets,
     const int32_t* __restrict__ soffsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int64_t super_capacity, unsigned* __restrict__ cursor,
-    uint2* __restrict__ records, int dbg) {
+    uint2* __restrict__ records SC_DIAG_PARAM(dbg)) {
     extern __shared__ unsigned lds[];
     // the caller may have sized the buffers from a prediction: do nothing if they are too small
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     tab.b[lane] = pay;
     for (int q = 0; q < c; ++q) tab.owner[off + q] = (unsigned char)lane;
     __syncthreads();                       // hist zeroed, tables complete
-    if (dbg & 4) return;                   // diagnostic: price the load + table build alone
+    if (SC_DIAG_BIT(dbg, 4)) return;       // diagnostic: price the load + table build alone
 
     // decode pair number p -> bucket (and, for pass 2, everything the record needs)
     auto bucket_of = [&](int p, int& o, int& sx, int& sy) -> int {
@@ -698,14 +704,14 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
     }
     walk_big([&](int b, const Rect&, int, int, unsigned, unsigned) { atomicAdd(&hist[b], 1u); });
     __syncthreads();
-    if (dbg & 8) return;                   // diagnostic: ... and the counting pass
+    if (SC_DIAG_BIT(dbg, 8)) return;       // diagnostic: ... and the counting pass
     for (int b = threadIdx.x; b < n_sbuckets; b += FLAT_THREADS) {
         const unsigned cb = hist[b];
         if (cb) gbase[b] = (unsigned)soffsets[b] + atomicAdd(&cursor[b], cb);
         hist[b] = 0;
     }
     __syncthreads();
-    if (dbg & 2) return;
+    if (SC_DIAG_BIT(dbg, 2)) return;
     // pass 2: slots + records
     auto tile_mask = [&](int x0, int x1, int y0, int y1, int sx, int sy) -> unsigned {
         if (!g.ss) return 1u;
@@ -722,11 +728,11 @@ __global__ __launch_bounds__(FLAT_THREADS) void bin_scatter_flat_kernel(
         const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
         const uint4 B = tab.b[o];
         const unsigned mask = tile_mask((int)(B.x & 0xffffu), (int)(B.x >> 16), (int)(B.y & 0xffffu), (int)(B.y >> 16), sx, sy);
-        if (!(dbg & 1)) records[slot] = make_uint2(B.z, B.w | (mask << 28));
+        if (!SC_DIAG_BIT(dbg, 1)) records[slot] = make_uint2(B.z, B.w | (mask << 28));
     }
     walk_big([&](int b, const Rect& br, int sx, int sy, unsigned bd, unsigned bi) {
         const unsigned slot = gbase[b] + atomicAdd(&hist[b], 1u);
-        if (!(dbg & 1)) records[slot] = make_uint2(bd, bi | (tile_mask(br.x0, br.x1, br.y0, br.y1, sx, sy) << 28));
+        if (!SC_DIAG_BIT(dbg, 1)) records[slot] = make_uint2(bd, bi | (tile_mask(br.x0, br.x1, br.y0, br.y1, sx, sy) << 28));
     });
 }
 
@@ -758,7 +764,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
                                            const int32_t* __restrict__ offsets, int n_tiles_total,
                                            int64_t n_isects, int tile_bits, const int* tb, unsigned long long* table,
                                            int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
-                                           unsigned* totals, int dbg) {
+                                           unsigned* totals SC_DIAG_PARAM(dbg)) {
     constexpr int WAVES = THREADS / 64;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cam = sb / g.ST, srem = sb - cam * g.ST;
@@ -806,7 +812,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
         tend[k] = tok[k] ? ((tflat + 1 < n_tiles_total) ? offsets[tflat + 1] : (int)n_isects) : 0;
         hi_key[k] = ((long long)cam << (32 + tile_bits)) | ((long long)tile << 32);
     }
-    if (dbg & 1) return;
+    if (SC_DIAG_BIT(dbg, 1)) return;
     for (int r = 0; r < rounds; ++r) {
         const int i = r * THREADS + t;
         const unsigned long long key = (i < n) ? S[order ? order[i] : i] : 0ull;
@@ -818,7 +824,7 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
             if (((m >> k) & 1u) && tok[k]) {
                 const int pos = tbase[k] + (int)((base >> (16 * k)) & 0xffffu) + __popcll(bal & sc_lanemask_lt());
                 if (pos < tend[k]) {
-                    if (isect_ids && !(dbg & 16)) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
+                    if (isect_ids && !SC_DIAG_BIT(dbg, 16)) isect_ids[pos] = hi_key[k] | (long long)(key >> 32);
                     flatten_ids[pos] = (int32_t)((unsigned)key & ID_MASK);
                 }
             }
@@ -849,8 +855,8 @@ __host__ __device__ inline size_t sort_lds_bytes(int cap) {
 __device__ __forceinline__ void sort_segment(
     const uint2* __restrict__ recs, int n, int sb, const int* tb, int cap, const Geo& g,
     const int32_t* __restrict__ offsets, int n_tbuckets, int64_t n_isects, int tile_bits,
-    unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out,
-    int dbg) {
+    unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out
+    SC_DIAG_PARAM(dbg)) {
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
     unsigned short* order = reinterpret_cast<unsigned short*>(B + cap);      // cap is a multiple of 256
     unsigned* boff = reinterpret_cast<unsigned*>(order + cap);              // [n + 1] fine-bucket counters
@@ -896,7 +902,7 @@ __device__ __forceinline__ void sort_segment(
         lo = red_lo[w] < lo ? red_lo[w] : lo;
         hi = red_hi[w] > hi ? red_hi[w] : hi;
     }
-    if (dbg & 4) return;                  // diagnostic: price the load + min / max alone (nothing is emitted)
+    if (SC_DIAG_BIT(dbg, 4)) return;      // diagnostic: price the load + min / max alone (nothing is emitted)
     const double s1 = (double)SS_NC / ((double)(hi - lo) + 1.0);
     // key -> (coarse bin, position inside the bin in [0, 1]); monotone in the key
     auto level1 = [&](unsigned long long K, float& frac) -> int {
@@ -927,7 +933,7 @@ __device__ __forceinline__ void sort_segment(
         coarse[t] = c | (run << 16);
     }
     __syncthreads();
-    if (dbg & 8) return;                  // diagnostic: ... and the coarse counting pass + scan
+    if (SC_DIAG_BIT(dbg, 8)) return;      // diagnostic: ... and the coarse counting pass + scan
     auto fine_of = [&](unsigned long long K) -> int {
         float frac;
         const unsigned cs = coarse[level1(K, frac)];
@@ -966,7 +972,7 @@ __device__ __forceinline__ void sort_segment(
         }
     }
     __syncthreads();
-    if (dbg & 32) return;                 // diagnostic: ... and the fine counting pass + scan
+    if (SC_DIAG_BIT(dbg, 32)) return;     // diagnostic: ... and the fine counting pass + scan
     // scatter: after this pass boff[j] is the END of fine bucket j (== start of j + 1)
 #pragma unroll
     for (int k = 0; k < SS_RPT; ++k) {
@@ -979,7 +985,7 @@ __device__ __forceinline__ void sort_segment(
         }
     }
     __syncthreads();
-    if (dbg & 2) return;
+    if (SC_DIAG_BIT(dbg, 2)) return;
     // rank inside the fine bucket by (depth bits, flat id) -> order[rank] = position in B.  Consecutive
     // threads take consecutive positions, i.e. neighbouring buckets: the LDS reads stay close together.
     // The bucket of position p was left in order[p] by the scatter (2 bytes instead of re-deriving it from the
@@ -1006,7 +1012,7 @@ __device__ __forceinline__ void sort_segment(
     }
     __syncthreads();
     emit_tiles<SS_THREADS>(B, order, n, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tb, table, isect_ids,
-                           flatten_ids, totals, dbg);
+                           flatten_ids, totals SC_DIAG_ARG(dbg));
     if (totals_out) {
         __syncthreads();
         if (t < 4) totals_out[t] = totals[t];
@@ -1047,7 +1053,7 @@ __device__ __forceinline__ void sort_heavy_segment(
         __syncthreads();
         int tbl[4] = {tbr[0], tbr[1], tbr[2], tbr[3]};
         emit_tiles<SS_THREADS>(B, nullptr, m, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tbl, table, isect_ids,
-                               flatten_ids, tot, 0);
+                               flatten_ids, tot SC_DIAG_ARG(0));
         __syncthreads();
         if (t < 4) tbr[t] += (int)tot[t];
         __syncthreads();
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
     const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
     Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int64_t super_capacity, int tile_bits, int cap,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, int dbg) {
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids SC_DIAG_PARAM(dbg)) {
     extern __shared__ __align__(16) unsigned char smem[];
     // the SAME three comparisons in every kernel of the sort phase and in the host wrapper
     // (rendering._bin_launch_ran): a launch either runs in full or not at all
@@ -1080,7 +1086,7 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
                                meta[0], tile_bits, smem, isect_ids, flatten_ids);
         else
             sort_segment(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem,
-                         isect_ids, flatten_ids, nullptr, dbg);
+                         isect_ids, flatten_ids, nullptr SC_DIAG_ARG(dbg));
         return;
     }
     const int sb = (int)blockIdx.x - seg_bound;
@@ -1091,7 +1097,7 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
     if (threadIdx.x < 4) tb_s[threadIdx.x] = 0;
     __syncthreads();
     sort_segment(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
-                 flatten_ids, nullptr, dbg);
+                 flatten_ids, nullptr SC_DIAG_ARG(dbg));
 }
 
 // ---- isect_ids on demand ------------------------------------------------------------------------------------
@@ -1149,8 +1155,8 @@ __device__ __forceinline__ void for_records(const uint2* __restrict__ src, int n
 __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
     const uint2* __restrict__ records, uint2* __restrict__ temp, Segment* __restrict__ segs,
     unsigned* __restrict__ n_segs, int seg_bound, const int32_t* __restrict__ soffsets, int n_sbuckets,
-    const int64_t* __restrict__ meta, int64_t capacity, int64_t rec_capacity, int64_t super_capacity, int cap,
-    int dbg) {
+    const int64_t* __restrict__ meta, int64_t capacity, int64_t rec_capacity, int64_t super_capacity, int cap
+    SC_DIAG_PARAM(dbg)) {
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     // The keys of a street-scene bucket sit in a few narrow depth bands, so many lanes of a wave hit the SAME
     // few counters and an LDS atomic instruction serialises identical addresses: every bin counter has 8
@@ -1196,7 +1202,7 @@ __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
             lo = red_lo[w] < lo ? red_lo[w] : lo;
             hi = red_hi[w] > hi ? red_hi[w] : hi;
         }
-        if (dbg & 8) continue;                      // diagnostic: price the min / max pass alone (no segments are made)
+        if (SC_DIAG_BIT(dbg, 8)) continue;          // diagnostic: price the min / max pass alone (no segments are made)
         const double sc = (double)BS_NB / ((double)(hi - lo) + 1.0);
         auto bin_of = [&](unsigned long long K) -> int {
             const int b = (int)((double)(K - lo) * sc);
@@ -1204,7 +1210,7 @@ __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
         };
         for_records(src, n, [&](uint2 rc) { atomicAdd(&hist[bin_of(rec_key60(rc)) * REP + (lane & (REP - 1))], 1u); });
         __syncthreads();
-        if (dbg & 16) continue;                     // diagnostic: ... and the histogram pass
+        if (SC_DIAG_BIT(dbg, 16)) continue;         // diagnostic: ... and the histogram pass
         // thread t owns bin t.  light = exclusive prefix of the light bins' counts, H = heavy bins before t.
         unsigned c = 0;
 #pragma unroll
@@ -1270,7 +1276,7 @@ __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
         // copy pass: records grouped by range; per range, how many of its records fall in each of the 4 tiles
         // (replicated counters again: a range's records are many lanes of every wave)
         uint2* dst = temp + s;
-        if (!(dbg & 4))        // diagnostic: skip the copy pass (segments then hold stale records; every consumer bounds-checks)
+        if (!SC_DIAG_BIT(dbg, 4))        // diagnostic: skip the copy pass (segments then hold stale records; every consumer bounds-checks)
         for_records(src, n, [&](uint2 rc) {
             const unsigned r = hist[bin_of(rec_key60(rc)) * REP];
             const unsigned slot = rstart[r] + atomicAdd(&rcur[r], 1u);
@@ -1482,8 +1488,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
                        depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
                        meta_mirror, seq, (const unsigned*)whint, (const unsigned*)wstat, tile_order, L.ntb, staged,
-                       g_sc_raster_split, g_sc_raster_bwd_split ? 0 : 1,
-                       g_sc_debug[1] >> 16);
+                       g_sc_raster_split, g_sc_raster_bwd_split ? 0 : 1 SC_DIAG_ARG(g_sc_debug[1] >> 16));
     SC_LAUNCH_CHECK();
     return SC_OK;
 }
@@ -1557,14 +1562,14 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     if (CN > 262144)
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS, 64>), dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
                            dim3(FLAT_THREADS), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
-                           L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records,
-                           g_sc_debug[0]);
+                           L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records
+                           SC_DIAG_ARG(g_sc_debug[0]));
     else {
         constexpr int gpb = FLAT_THREADS_SMALL / 64 * 16;
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>), dim3((unsigned)((CN + gpb - 1) / gpb)),
                            dim3(FLAT_THREADS_SMALL), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS_SMALL / 64) * sizeof(FlatTab), s,
                            sorted, cmeta, L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor,
-                           records, g_sc_debug[0]);
+                           records SC_DIAG_ARG(g_sc_debug[0]));
     }
     SC_LAUNCH_CHECK();
     const int tile_bits = sc_bits_for(L.g.T);
@@ -1572,13 +1577,13 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     if (big) {
         const int bgrid = L.nsb;          // one workgroup per super-tile: the hardware balances the oversized ones
         hipLaunchKernelGGL(big_split_kernel, dim3(bgrid), dim3(BS_THREADS), 0, s, (const uint2*)records, temp, segs,
-                           n_segs, seg_bound, soffsets, L.nsb, meta_dev, capacity, rec_capacity, super_capacity, cap, g_sc_debug[3]);
+                           n_segs, seg_bound, soffsets, L.nsb, meta_dev, capacity, rec_capacity, super_capacity, cap SC_DIAG_ARG(g_sc_debug[3]));
         SC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(super_sort_kernel, dim3((unsigned)(seg_bound + L.nsb)), dim3(SS_THREADS), sort_lds_bytes(cap), s,
                        (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
                        (const unsigned*)n_segs, seg_bound, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
-                       capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids, g_sc_debug[2]);
+                       capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -140,7 +140,8 @@ __global__ void raster_fwd_ref_kernel(
 // NSUB: 1 = whole tile, 2 = half (8 rows), 4 = quarter (4 rows); `sub` = which one.
 // PACKED: `means2d` points to one 48-B record per Gaussian, (x, y, conic a, b | conic c, opacity, colour 0, 1 |
 // colour 2, 3, -, -), written by projection_sh_fwd_kernel for the fused forward: one gather line per splat instead of four.
-template <int CDIM, bool TRACK, int NSUB, bool PACKED = false>
+// ED: the "RGB+ED" epilogue (sc_rasterize_fwd_ed; CDIM == 4): channel 3 leaves as depth sum / max(alpha, 1e-10).
+template <int CDIM, bool TRACK, int NSUB, bool PACKED = false, bool ED = false>
 __device__ __forceinline__ void raster_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -148,8 +149,8 @@ __device__ __forceinline__ void raster_item(
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg, int tflat, int sub,
-    float4* xyoa_s, float4* bck_s, float4* col_s, int32_t* __restrict__ tile_work) {
+    int32_t* __restrict__ last_ids, int tflat, int sub,
+    float4* xyoa_s, float4* bck_s, float4* col_s, int32_t* __restrict__ tile_work SC_DIAG_PARAM(dbg)) {
     constexpr int SB = 2;                 // splats staged per lane per batch
     constexpr int B = 64 * SB;            // batch size
     constexpr int NP = NSUB == 1 ? 2 : 1; // pixel PAIRS per lane
@@ -305,7 +306,7 @@ __device__ __forceinline__ void raster_item(
             g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
         }
         // ---- blend ---------------------------------------------------------------------------------
-        if (dbg & 1) bsz = 0;
+        if (SC_DIAG_BIT(dbg, 1)) bsz = 0;      // diagnostic build only: price the kernel without its blend loop
         if (bsz > 0) {
             // one blended splat: a = (mx, my, log2 op, B2), bc = (A2, C2, sorted index, -), c = colour
             auto blend = [&](const float4& a, const float4& bc, const float4& c) {
@@ -377,7 +378,7 @@ __device__ __forceinline__ void raster_item(
             }
             // "RGB+ED" epilogue (sc_rasterize_fwd_ed): expected depth = depth sum / max(alpha, 1e-10),
             // the caller's renderer.py:284 / gsplat rasterization() post-step, as one IEEE divide
-            if (dbg & 0x100) o.w = o.w / fmaxf(1.0f - Tk, 1e-10f);
+            if (ED) o.w = o.w / fmaxf(1.0f - Tk, 1e-10f);
             *reinterpret_cast<float4*>(render_colors + pix * 4) = o;
         } else {
 #pragma unroll
@@ -389,7 +390,7 @@ __device__ __forceinline__ void raster_item(
     if (tile_work && lane == 0) tile_work[tflat] = walked;     // halves: the later finisher's count stands
 }
 
-template <int CDIM, bool TRACK, bool PACKED = false>
+template <int CDIM, bool TRACK, bool PACKED = false, bool ED = false>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -397,8 +398,8 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     int width, int height, int tile_width, int tile_height, int total_tiles,
     const int32_t* __restrict__ isect_offsets, const int32_t* __restrict__ flatten_ids, int n_isects,
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
-    int32_t* __restrict__ last_ids, int dbg, int map_mode, const int32_t* __restrict__ order,
-    int32_t* __restrict__ tile_work) {
+    int32_t* __restrict__ last_ids, int map_mode, const int32_t* __restrict__ order,
+    int32_t* __restrict__ tile_work SC_DIAG_PARAM(dbg)) {
     constexpr int B = 128;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
     __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
@@ -433,14 +434,15 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
         }
     }
     if (kind == 0)
-        raster_item<CDIM, TRACK, 1, PACKED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 1, PACKED, ED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
-                                    render_colors, render_alphas, last_ids, dbg, tflat, 0, xyoa_s, bck_s, col_s, tile_work);
+                                    render_colors, render_alphas, last_ids, tflat, 0, xyoa_s, bck_s, col_s, tile_work
+                                    SC_DIAG_ARG(dbg));
     else
-        raster_item<CDIM, TRACK, 2, PACKED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 2, PACKED, ED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
-                                    render_colors, render_alphas, last_ids, dbg, tflat, kind - 1, xyoa_s, bck_s, col_s,
-                                    tile_work);
+                                    render_colors, render_alphas, last_ids, tflat, kind - 1, xyoa_s, bck_s, col_s,
+                                    tile_work SC_DIAG_ARG(dbg));
 }
 
 }  // namespace
@@ -459,20 +461,14 @@ extern "C" int sc_tile_order_len(int total_tiles) {
     return total_tiles < 0 ? 0 : sc_tile_order_fwd_items(total_tiles) + total_tiles + 2;     // + "second list present" + view slot
 }
 
-extern "C" size_t sc_rasterize_workspace_bytes(int C, int tile_width, int tile_height) {
-    (void)C; (void)tile_width; (void)tile_height;
-    return 256;       // the shipped kernels need no scratch
-}
-
 static int rasterize_fwd_impl(const float* means2d, const float* conics, const float* colors,
                               const float* opacities, const float* backgrounds,
                               const uint8_t* tile_masks, int C, int N, int D, int width, int height,
                               int tile_size, int tile_width, int tile_height,
                               const int32_t* isect_offsets, const int32_t* flatten_ids,
                               int64_t n_isects, float* render_colors, float* render_alphas,
-                              int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work, void* workspace,
-                              size_t ws_bytes, sc_stream_t stream, int epilogue) {
-    (void)workspace; (void)ws_bytes;
+                              int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work,
+                              sc_stream_t stream, int epilogue) {
     if (C < 0 || N < 0 || D < 1 || D > SC_MAX_CDIM || width <= 0 || height <= 0) return SC_EINVAL;
     if (tile_size < 1 || tile_size > 32 || tile_width <= 0 || tile_height <= 0) return SC_EINVAL;
     if (n_isects < 0 || n_isects > 0x7fffffffLL) return SC_EINVAL;
@@ -489,23 +485,23 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     // the depth-normalising epilogue exists in the wave-per-tile kernel with 4 channels only
     if (epilogue && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
     if (packed && last_ids) return SC_EUNSUPPORTED;
-    const int kdbg = g_sc_debug[1] | ((epilogue & 1) ? 0x100 : 0);
+    const bool ed = (epilogue & 1) != 0;       // depth-normalising epilogue: a template parameter of the kernel
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
         const int n_blocks = tile_order ? sc_tile_order_fwd_items(total_tiles) : total_tiles;
-#define SC_LAUNCH_WAVE(CD, TR)                                                                                      \
-    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d,           \
+        if (ed && last_ids) return SC_EUNSUPPORTED;       // (the epilogue is an inference form: sc_rasterize_fwd_ed passes none)
+#define SC_LAUNCH_WAVE(CD, TR, PK, EDP)                                                                             \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR, PK, EDP>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
-                       render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work)
-        if (packed)
-            hipLaunchKernelGGL((raster_fwd_wave_kernel<4, false, true>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d,
-                               conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,
-                               tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,
-                               render_alphas, last_ids, kdbg, g_sc_raster_map, tile_order, tile_work);
-        else if (D == 4) { if (last_ids) SC_LAUNCH_WAVE(4, true); else SC_LAUNCH_WAVE(4, false); }
-        else { if (last_ids) SC_LAUNCH_WAVE(3, true); else SC_LAUNCH_WAVE(3, false); }
+                       render_alphas, last_ids, g_sc_raster_map, tile_order, tile_work SC_DIAG_ARG(g_sc_debug[1] & 0xff))
+        if (packed) { if (ed) SC_LAUNCH_WAVE(4, false, true, true); else SC_LAUNCH_WAVE(4, false, true, false); }
+        else if (D == 4) {
+            if (ed) SC_LAUNCH_WAVE(4, false, false, true);
+            else if (last_ids) SC_LAUNCH_WAVE(4, true, false, false);
+            else SC_LAUNCH_WAVE(4, false, false, false);
+        } else { if (last_ids) SC_LAUNCH_WAVE(3, true, false, false); else SC_LAUNCH_WAVE(3, false, false, false); }
 #undef SC_LAUNCH_WAVE
         SC_LAUNCH_CHECK();
         return SC_OK;
@@ -537,11 +533,11 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
                                 int tile_size, int tile_width, int tile_height,
                                 const int32_t* isect_offsets, const int32_t* flatten_ids,
                                 int64_t n_isects, float* render_colors, float* render_alphas,
-                                int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work, void* workspace,
-                                size_t ws_bytes, sc_stream_t stream) {
+                                int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work,
+                                sc_stream_t stream) {
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
-                              render_colors, render_alphas, last_ids, tile_order, tile_work, workspace, ws_bytes, stream, 0);
+                              render_colors, render_alphas, last_ids, tile_order, tile_work, stream, 0);
 }
 
 extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,
@@ -550,11 +546,10 @@ extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, co
                                    int tile_size, int tile_width, int tile_height,
                                    const int32_t* isect_offsets, const int32_t* flatten_ids,
                                    int64_t n_isects, float* render_colors, float* render_alphas,
-                                   const int32_t* tile_order, int32_t* tile_work, void* workspace, size_t ws_bytes,
-                                   sc_stream_t stream) {
+                                   const int32_t* tile_order, int32_t* tile_work, sc_stream_t stream) {
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
-                              render_colors, render_alphas, nullptr, tile_order, tile_work, workspace, ws_bytes, stream, 1);
+                              render_colors, render_alphas, nullptr, tile_order, tile_work, stream, 1);
 }
 
 
@@ -570,6 +565,6 @@ extern "C" int sc_rasterize_fwd_packed(const float* records, const float* backgr
     if (records && ((uintptr_t)records & 15)) return SC_EINVAL;
     return rasterize_fwd_impl(records, nullptr, nullptr, nullptr, backgrounds, tile_masks, C, N, 4, width, height, 16,
                               tile_width, tile_height, isect_offsets, flatten_ids, n_isects, render_colors,
-                              render_alphas, nullptr, tile_order, tile_work, nullptr, 0, stream,
+                              render_alphas, nullptr, tile_order, tile_work, stream,
                               2 | (depth_normalise ? 1 : 0));
 }

@@ -18,12 +18,26 @@
         if (e__ != hipSuccess) return (int)e__;             \
     } while (0)
 
-// Diagnostic knobs (sc_set_option("debug0".."debug3", v)); 0 in production.  A non-zero value makes
-// a kernel SKIP part of its work so that the part can be priced; outputs are then invalid.
-// RULE (two GPU memory faults were diagnostic knobs): a skip must leave every index
-// that is derived from the skipped producer IN BOUNDS for every consumer -- skip stores, never the
-// computation of counts / offsets other code indexes with, and bound-check at the consumer anyway.
+// DIAGNOSTIC BUILD ONLY (-DSC_DIAG: `python -m street_crafter_amd.build --diag` ->
+// lib/libstreet_crafter_hip_diag.so, loaded explicitly by tools/exp_*.py through _lib.use_diagnostic_build()).
+// The shipped library carries NO diagnostic switch: without SC_DIAG the macros below remove the `dbg` kernel
+// parameters, the host-side knob array and every skip branch from the compiled code, and
+// sc_set_option("debug0".."debug3") is an unknown key.  (Both GPU memory faults of rounds 1 and 2 were these
+// knobs reaching production launches: DESIGN.md section 8.)
+// In the diagnostic build a non-zero knob makes a kernel SKIP part of its work so that the part can be priced;
+// outputs are then invalid.  RULE: a skip must leave every index that is derived from the skipped producer IN
+// BOUNDS for every consumer -- skip stores, never the computation of counts / offsets other code indexes with,
+// and bound-check at the consumer anyway.
+#ifdef SC_DIAG
 extern int g_sc_debug[4];
+#define SC_DIAG_PARAM(name) , int name            /* trailing kernel / function parameter */
+#define SC_DIAG_ARG(value) , (value)              /* ... and its argument at the call / launch site */
+#define SC_DIAG_BIT(name, mask) (((name) & (mask)) != 0)
+#else
+#define SC_DIAG_PARAM(name)
+#define SC_DIAG_ARG(value)
+#define SC_DIAG_BIT(name, mask) false
+#endif
 extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
 // VIEW SLOTS: the rasterizer's work hint is kept per VIEW (a street rig renders front / front-left / front-right in
 // turn: a frame must not find the hint another camera left).  The count launch (view_slot_lookup, isect_bin.hip)

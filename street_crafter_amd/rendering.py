@@ -568,7 +568,7 @@ class _Rasterize(torch.autograd.Function):
                                         _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
                                         _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
                                         _p(render_colors), _p(render_alphas), _p(last_ids), _p(order), _p(work),
-                                        None, 0, _stream(means2d)),
+                                        _stream(means2d)),
                    "sc_rasterize_fwd")
         e = torch.empty(0, device=dev)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,
@@ -819,15 +819,15 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
                 int(tile_size), tile_width, tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
                 _p(render_colors), _p(render_alphas))
         if render_mode == "RGB+ED":
-            rc = lib.sc_rasterize_fwd_ed(*args, *sch, None, 0, st)
+            rc = lib.sc_rasterize_fwd_ed(*args, *sch, st)
             if rc == -3:          # the reference-shaped raster kernel is selected: plain launch + the torch post-step
-                _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
+                _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, st), "sc_rasterize_fwd")
                 render_colors = torch.cat([render_colors[..., :-1],
                                            render_colors[..., -1:] / render_alphas.clamp(min=1e-10)], dim=-1)
             else:
                 _lib.check(rc, "sc_rasterize_fwd_ed")
         else:
-            _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, None, 0, st), "sc_rasterize_fwd")
+            _lib.check(lib.sc_rasterize_fwd(*args, None, *sch, st), "sc_rasterize_fwd")
     meta = _FusedMeta({"radii": radii, "means2d": means2d, "depths": depths,
                        "tile_width": tile_width, "tile_height": tile_height, "tiles_per_gauss": tiles_per_gauss,
                        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets,

@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from oracle import gsplat_oracle_c as OC  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)

@@ -59,9 +59,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.sc_sh_fwd(5, None, None, None, 4, 36, None, None) == -1              # degree > 4
     assert lib.sc_sh_fwd(3, None, None, None, 4, 9, None, None) == -1               # K < 16
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 33, 64, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None, None, None, 0, None) == -1        # D > 32
+                                None, None, 0, None, None, None, None, None, None) == -1        # D > 32
     assert lib.sc_rasterize_fwd(None, None, None, None, None, None, 1, 4, 3, 65, 64, 16, 4, 4,
-                                None, None, 0, None, None, None, None, None, None, 0, None) == -1        # tiles too few
+                                None, None, 0, None, None, None, None, None, None) == -1        # tiles too few
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 10, 65, None, 0, None) == -1
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 1, 40, None, 0, None) == 0   # n<=1 no-op
     # fused forward entries
@@ -77,7 +77,7 @@ def test_argument_validation_without_gpu(lib):
                                        None) == -1
     assert lib.sc_records_unpack(None, 8, None, None, None, None) == -1 and lib.sc_records_unpack(None, 0, None, None, None, None) == 0
     assert lib.sc_rasterize_fwd_ed(None, None, None, None, None, None, 1, 4, 3, 64, 64, 16, 4, 4,
-                                   None, None, 0, None, None, None, None, None, 0, None) in (-1, -3)   # needs D == 4
+                                   None, None, 0, None, None, None, None, None) in (-1, -3)   # needs D == 4
     assert lib.sc_isect_bin_count(None, None, None, 1, 8, 16, 4, 4, None, None, None, None, 0, None, 0, None, None,
                                   None, None, None) == -1
     assert lib.sc_view_slots() == 8 and lib.sc_view_registry_words() == 4 + 4 * 8
@@ -174,6 +174,42 @@ def test_product_path_never_imports_oracle():
     assert not bad, bad
 
 
+def test_shipped_library_has_no_diagnostic_switches(lib):
+    """the `debug0..3` skip switches (two GPU memory faults in two rounds) exist only in the
+    separate diagnostic build.  The shipped library does not know the keys and exports no knob array; nothing in the
+    product packages, the harness, tests/ or bench.py asks for the diagnostic build; the transcribed caller sequence
+    lives outside the product package."""
+    import subprocess
+    from street_crafter_amd import _lib
+    for k in range(4):
+        assert lib.sc_set_option(f"debug{k}".encode(), 0) == -1
+        with pytest.raises(ValueError):
+            _lib.set_option(f"debug{k}", 1)
+    assert b"DIAGNOSTIC" not in lib.sc_version()
+    syms = subprocess.run(["nm", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "g_sc_debug" not in syms
+    assert _lib._path == _lib.LIB_PATH
+    users = []
+    for top in ("street_crafter_amd", "gsplat", "simple_knn", "harness", "tests"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py") and f not in ("_lib.py", "build.py", "test_capi_cpu.py"):     # (build.py: its docstring)
+                    if "use_diagnostic_build" in open(os.path.join(dirpath, f)).read():
+                        users.append(os.path.join(dirpath, f))
+    for f in ("bench.py", "__graft_entry__.py"):
+        if "use_diagnostic_build" in open(os.path.join(ROOT, f)).read():
+            users.append(f)
+    assert not users, users
+    assert not os.path.exists(os.path.join(ROOT, "street_crafter_amd", "pipeline.py"))
+    # no source of the product reads a knob outside the SC_DIAG macros
+    for f in os.listdir(os.path.join(ROOT, "street_crafter_amd", "csrc")):
+        src = open(os.path.join(ROOT, "street_crafter_amd", "csrc", f)).read()
+        for line in src.splitlines():
+            if "g_sc_debug" in line:
+                assert "SC_DIAG" in line or line.lstrip().startswith(("//", "extern int g_sc_debug", "int g_sc_debug",
+                                                                       "const int prev = g_sc_debug", "g_sc_debug[key")), (f, line)
+
+
 def test_densification_stats_mirror_cpu():
     """Host logic of the densification-statistics consumer (street_gaussian_model.py:487-521) on CPU
     tensors: per-model slicing, absgrad/grad columns, pixel scaling, visibility gating, NaN -> 0."""
@@ -218,7 +254,7 @@ def test_bench_algorithmic_bytes_are_the_survey_formula():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    from street_crafter_amd.pipeline import algorithmic_bytes
+    from harness.caller import algorithmic_bytes
     N, I, W, H = 1_000_000, 19_753_547, 1920, 1280
     P, T = W * H, 120 * 80
     for K, per_gauss in ((4, 197), (16, 341)):

@@ -478,10 +478,10 @@ def _pipeline_inputs(n, cam, seed, **kw):
 @pytest.mark.parametrize("variant", [0, 3])
 @pytest.mark.parametrize("w,h", [(256, 160), (200, 120)])
 def test_full_pipeline_vs_oracle(ops, variant, w, h):
-    """The caller's whole sequence (pipeline.render_gaussians == render_kernel_gsplat) vs the oracle:
+    """The caller's whole sequence (harness.caller.render_gaussians == render_kernel_gsplat) vs the oracle:
     ints bit-exact, pixels within tolerance, last_ids-dependent outputs consistent."""
     from street_crafter_amd import _lib
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     cam = make_camera(w, h, 280.0, 280.0)
     sc, exp = _pipeline_inputs(8000, cam, 31, z_range=(1.0, 40.0), scale_range=(0.01, 0.3))
     prev = _lib.set_option("raster_fwd", variant)
@@ -738,7 +738,7 @@ def test_train_step_at_config2_full_size(ops):
     properties -- the shipped backward (one wave per tile) against the reference-shaped kernel, which the small
     tests pin to autograd; every gradient finite; absgrad >= |grad| and zero exactly where nothing was rendered."""
     from street_crafter_amd import _lib
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     W, H = 1600, 1066
     cam = make_camera(W, H, 2050.0 * W / 1920.0, 2050.0 * W / 1920.0).to(DEV)
     base = make_scene(1_000_000)
@@ -851,7 +851,7 @@ def test_rasterize_backward_wave_matches_reference(ops, n, w, h, seed):
     (variant 0, itself checked against autograd above) through the whole train-mode render, on
     scenes with several staging batches per tile and both staging sub-batches populated."""
     from street_crafter_amd import _lib
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     cam = make_camera(w, h, 2050.0 * w / 1920.0, 2050.0 * w / 1920.0).to(DEV)
     target = torch.rand(3, h, w, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
     grads = []
@@ -876,7 +876,7 @@ def test_rasterize_backward_wave_matches_reference(ops, n, w, h, seed):
 def test_train_mode_contract_retain_grad_and_absgrad(ops):
     """What train.py:236 + street_gaussian_model.py:505-508 rely on: viewspace_points (a non-leaf
     output of the projection) keeps .grad after backward and gains .absgrad."""
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     cam = make_camera(160, 96, 180.0, 180.0).to(DEV)
     sc = make_scene(2500, seed=2, z_range=(1.0, 30.0), scale_range=(0.02, 0.3)).to(DEV)
     for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.sh):
@@ -997,9 +997,9 @@ def test_rasterization_other_modes_vs_oracle(ops, render_mode, rasterize_mode, d
 
 
 def test_rasterization_fused_equals_reference_caller_sequence(ops):
-    """The fused one-call path against the caller's hand-written sequence (pipeline.render_gaussians =
+    """The fused one-call path against the caller's hand-written sequence (harness.caller.render_gaussians =
     renderer.py:186-302) on the same camera, camera centre taken from the Camera as the reference does."""
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     sc = make_scene(50_000, seed=5).to(DEV)
     cam = make_camera(800, 528, 2050.0 * 800 / 1920, 2050.0 * 800 / 1920).to(DEV)
     with torch.no_grad():
@@ -1255,7 +1255,7 @@ def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
     keep them, a bank only changes when its own camera renders, the image never depends on any of it, a camera that
     turns slowly keeps its slot, and a ninth view takes over the least recently used slot."""
     from street_crafter_amd import _lib, rendering
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     from street_crafter_amd.scenes import make_street_scene
     lib = _lib.load()
     K_SLOTS = lib.sc_view_slots()
@@ -1327,7 +1327,7 @@ def test_speculative_sort_is_sized_for_the_fullest_of_the_recent_views(ops):
     that is enqueued before the counts are known must be sized for the fuller view after it has been seen once
     (sized by the previous call alone it missed on every switch back to it); the frames do not change."""
     from street_crafter_amd import rendering
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     w, h, n = 640, 400, 40_000
     sc = make_scene(n, seed=17, z_range=(1.0, 30.0)).to(DEV)
     cams = [make_camera(w, h, 500.0, 500.0, yaw=0.0).to(DEV), make_camera(w, h, 500.0, 500.0, yaw=0.75).to(DEV)]
@@ -1383,7 +1383,7 @@ def test_tile_dispatch_order_in_training(ops, shape, bwd_split):
     the same gradients) or, `raster_bwd_split` 0, whole tiles in the same order; gradients match the plain dispatch
     up to fp32 summation order.  "even": the halves are the last tiles of the list; "street": the heaviest."""
     from street_crafter_amd import _lib, rendering
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     from street_crafter_amd.scenes import make_street_scene
     w, h = 400, 272
     cam = make_camera(w, h, 2050.0 * w / 1920.0, 2050.0 * w / 1920.0).to(DEV)
@@ -1435,7 +1435,7 @@ def test_densification_statistics_consumer_vs_oracle(ops):
     the reference's consumer (densify_stats.py mirrors street_gaussian_model.py:487-521) over two
     cameras and two sub-model ranges, against the same consumer fed by the float64 oracle."""
     from street_crafter_amd.densify_stats import DensificationStats, accumulate_from_render
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     W, H = 128, 96
     sc = make_scene(2500, seed=4, z_range=(1.0, 30.0), scale_range=(0.02, 0.3))
     ranges = {"background": (0, 1800), "obj_001": (1800, 2500)}
@@ -1492,7 +1492,7 @@ def test_render_sharded_two_frames_in_flight_is_identical(ops):
     """dist.render_sharded with frames alternating over two HIP streams returns the same uint8 frames as
     the sequential loop (single process: the gather is the identity)."""
     from street_crafter_amd.dist import render_sharded, to_uint8_frame
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     sc = make_scene(60_000, seed=12).to(DEV)
     cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.02 * i, shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(6)]
 
@@ -1516,7 +1516,7 @@ def test_two_host_threads_render_on_one_device(ops):
     no GIL): every frame equals the one rendered alone."""
     import threading
     from street_crafter_amd.dist import to_uint8_frame
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     scenes = [make_scene(50_000, seed=31).to(DEV), make_scene(80_000, seed=32, z_range=(1.0, 40.0)).to(DEV)]
     # (cameras 0.03 rad apart at first, then 0.3: the second half lands in different VIEW SLOTS, so the two threads'
     # count launches look up, take over and update the device-side view registry at the same time)
@@ -1560,7 +1560,7 @@ def test_scene_files_drive_the_renderer(ops, tmp_path):
     colour), read back and composed, renders bit-identically to the in-memory composition; and an actor
     under pose (q, t) renders exactly like the same Gaussians moved by hand into the background."""
     from street_crafter_amd import scene_io as sio
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     bk = sio.scene_to_submodel(make_scene(8000, seed=8, z_range=(4.0, 40.0)))
     g = torch.Generator().manual_seed(2)
     n = 1500
@@ -1605,7 +1605,7 @@ def test_novel_view_two_pass_frame_vs_oracle(ops):
     pixels stable in both passes; the fused composite + clamp + uint8 kernel equals the torch composition bit for
     bit in both of the reference's rounding modes; the rasterization()-based fast path gives the same frame."""
     from street_crafter_amd.dist import to_uint8_frame
-    from street_crafter_amd.pipeline import render_novel_view, render_novel_view_u8
+    from harness.caller import render_novel_view, render_novel_view_u8
     from street_crafter_amd.scenes import make_street_scene
     W, H = 320, 208
     cam = make_camera(W, H, 340.0, 340.0)
@@ -1715,7 +1715,7 @@ def test_full_resolution_s100k_against_committed_digest(ops, golden_dir):
     the bit-exact float tensors, 8x8 block means of the image.  No oracle run on the box."""
     import json
     import zlib
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     from street_crafter_amd.scenes import make_scene_portable
     dg = json.load(open(os.path.join(golden_dir, "s100k_fullres_digest.json")))
     crc_np = lambda a: int(zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xffffffff)
@@ -1754,7 +1754,7 @@ def test_full_size_properties_1m(ops):
     """BASELINE config: 1 M Gaussians, 1920x1280.  Oracle for the streaming/integer stages
     (vectorised numpy is fast enough); size-independent properties for the blend."""
     from street_crafter_amd import _lib, rendering
-    from street_crafter_amd.pipeline import render_gaussians
+    from harness.caller import render_gaussians
     sc = make_scene(1_000_000)
     cam = make_camera()
     scd, camd = sc.to(DEV), cam.to(DEV)

@@ -177,7 +177,7 @@ def test_oracle_fixture_drift(golden_dir):
 
 
 def test_algorithmic_bytes_formula():
-    from street_crafter_amd.pipeline import algorithmic_bytes
+    from harness.caller import algorithmic_bytes
     n, i = 1_000_000, 8_000_000
     assert algorithmic_bytes(n, i, 1920, 1280) == 197 * n + 88 * i + 24 * 1920 * 1280 + 4 * 9600
     assert algorithmic_bytes(n, 0, 1920, 1280, sh_bases=16) - 24 * 1920 * 1280 - 4 * 9600 == 341 * n

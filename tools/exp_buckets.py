@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "street1m"

@@ -12,9 +12,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from street_crafter_amd import _lib, rendering  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
+_lib.use_diagnostic_build()            # debug0..3 exist in lib/libstreet_crafter_hip_diag.so only (build.py --diag)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 STREET = len(sys.argv) > 3 and sys.argv[3] == "street"

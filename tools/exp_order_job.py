@@ -7,9 +7,10 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from street_crafter_amd import _lib  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
+_lib.use_diagnostic_build()            # the stage stamps exist in the diagnostic build only (build.py --diag)
 which = sys.argv[1] if len(sys.argv) > 1 else "s1m"
 sc = {"s1m": lambda: make_scene(1_000_000), "street1m": lambda: make_street_scene(1_000_000)[0],
       "sky": lambda: make_street_scene(1_000_000)[1]}[which]().to("cuda")

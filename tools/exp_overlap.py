@@ -13,7 +13,7 @@ import bench  # noqa: E402
 from gsplat.rendering import (fully_fused_projection, isect_offset_encode, isect_tiles, rasterize_to_pixels,  # noqa: E402
                               spherical_harmonics)
 from street_crafter_amd.dist import to_uint8_frame  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_scene  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 80

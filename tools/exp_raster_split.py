@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from street_crafter_amd import _lib  # noqa: E402
 from street_crafter_amd import rendering  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "s1m"
@@ -40,7 +40,7 @@ L_FWD = T + T // 8 + 8
 def launch(order=None, wk=scratch_work):
     _lib.check(lib.sc_rasterize_fwd(m2.data_ptr(), con.data_ptr(), col.data_ptr(), op.data_ptr(), None, None, 1, N, 4, W, H,
                                     16, tw, th, off.data_ptr(), fids.data_ptr(), fids.numel(), rc.data_ptr(), ra.data_ptr(),
-                                    None, order.data_ptr() if order is not None else None, wk.data_ptr(), None, 0, st), "fwd")
+                                    None, order.data_ptr() if order is not None else None, wk.data_ptr(), st), "fwd")
 
 
 def timeit(order=None):

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from gsplat.rendering import fully_fused_projection  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import Scene, make_scene, make_street_scene  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 30

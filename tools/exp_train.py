@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000

@@ -118,7 +118,7 @@ for it in range(ROUNDS):
     # the reference-shaped one, through the train-mode render of the first camera
     ok_bwd = True
     if n <= 150_000 and W * H <= 1600 * 1100:
-        from street_crafter_amd.pipeline import render_gaussians
+        from harness.caller import render_gaussians
         cam0 = cams[0].to("cuda")
         target = torch.rand(3, H, W, device="cuda")
         grads = []

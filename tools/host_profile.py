@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from street_crafter_amd.dist import to_uint8_frame  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
 from gsplat.rendering import rasterization  # noqa: E402
 

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from street_crafter_amd.dist import to_uint8_frame  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
 which = sys.argv[1] if len(sys.argv) > 1 else "s1m"
@@ -27,6 +27,7 @@ sc = sc.to("cuda")
 for k in range(4):
     if os.environ.get(f"SC_DEBUG{k}"):
         from street_crafter_amd import _lib
+        _lib.use_diagnostic_build()    # lib/libstreet_crafter_hip_diag.so (build.py --diag)
         _lib.set_option(f"debug{k}", int(os.environ[f"SC_DEBUG{k}"]))
 cam = make_camera().to("cuda")
 with torch.no_grad():

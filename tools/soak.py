@@ -8,7 +8,7 @@ import torch  # noqa: E402
 
 from gsplat.rendering import rasterization  # noqa: E402
 from street_crafter_amd.dist import to_uint8_frame  # noqa: E402
-from street_crafter_amd.pipeline import render_gaussians  # noqa: E402
+from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
