@@ -106,10 +106,16 @@ class FrameGatherer:
     batch, waits for everything and returns, on dst, the frames in global frame order.
 
     Frames may be produced on several HIP streams (frames in flight): the gather of a batch waits for
-    the recorded event of each of its frames."""
+    the recorded event of each of its frames.
+
+    With ONE rank there is nothing to gather and the frames are handed out as plain tensors -- unless
+    `force_collective=True`, which sends a world of one through the very same staging ring, stream events and
+    async `dist.gather` calls as a world of eight (needs an initialised process group): the only way to execute
+    the RCCL transport path on a one-GPU box (tests/test_gpu_parity.py::test_rccl_gather_ring_at_world_one,
+    `bench.py --force-gather`)."""
 
     def __init__(self, frame_shape: Sequence[int], device, dst: int = 0, group=None, batch: int = 8,
-                 ring: int = 3, keep: bool = True):
+                 ring: int = 3, keep: bool = True, force_collective: bool = False):
         self.dst, self.group = dst, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -117,8 +123,11 @@ class FrameGatherer:
         self.shape = tuple(int(v) for v in frame_shape)
         self.device = torch.device(device)
         self.keep = keep
+        if force_collective and not dist.is_initialized():
+            raise RuntimeError("FrameGatherer(force_collective=True) needs torch.distributed.init_process_group first")
         # world 1: nothing to gather, frames are handed out as fresh tensors and kept as they are
-        self._staging = [] if self.world == 1 else [
+        self._local = self.world == 1 and not force_collective
+        self._staging = [] if self._local else [
             torch.empty((self.batch, *self.shape), dtype=torch.uint8, device=self.device) for _ in range(self.ring)]
         self._single: Dict[int, torch.Tensor] = {}
         self._busy: List[Optional[object]] = [None] * self.ring    # outstanding work per ring entry
@@ -130,7 +139,7 @@ class FrameGatherer:
                       "host_s_waiting_for_ring": 0.0}
 
     def slot(self, round_index: int) -> torch.Tensor:
-        if self.world == 1:
+        if self._local:
             t = self._single.get(int(round_index))
             if t is None:
                 t = self._single[int(round_index)] = torch.empty(self.shape, dtype=torch.uint8, device=self.device)
@@ -150,7 +159,7 @@ class FrameGatherer:
     def submit(self, round_index: int, frame_u8: Optional[torch.Tensor] = None):
         """frame_u8: given only when the frame was NOT written into slot(round_index) (it is copied in)."""
         r = int(round_index)
-        if self.world == 1:
+        if self._local:
             t = self._single.pop(r, None) if frame_u8 is None else frame_u8
             self._single.pop(r, None)
             if t is None:
@@ -222,7 +231,8 @@ class FrameGatherer:
 
 
 def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,
-                   group=None, frames_in_flight: int = 2, batch: int = 8) -> Optional[List[torch.Tensor]]:
+                   group=None, frames_in_flight: int = 2, batch: int = 8, ring: int = 3,
+                   force_collective: bool = False) -> Optional[List[torch.Tensor]]:
     """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
     (None elsewhere).  n_frames must be a multiple of the world size (every round is one frame per
     rank); `render_frame(f)` returns the uint8 [H,W,3] frame f on this rank's device (if it accepts a
@@ -231,7 +241,8 @@ def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst
     frames_in_flight > 1 (HIP devices only): this rank's frames alternate over that many HIP streams, so
     the latency-bound intersection kernels of one frame run under the rasterizer of another (+20 % frames/s
     with 2 on S-1M, identical images).  Frames are independent, every operator launches on torch's current
-    stream, and the gather of a batch waits for the events of its frames."""
+    stream, and the gather of a batch waits for the events of its frames.
+    force_collective: see FrameGatherer (a world of one goes through the real gather ring)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if n_frames % world:
@@ -251,7 +262,9 @@ def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst
         try:
             if g is None:                 # the first frame tells the frame shape / device
                 first = render_frame(f)
-                g = FrameGatherer(first.shape, first.device, dst, group, batch=min(batch, len(mine)))
+                g = FrameGatherer(first.shape, first.device, dst, group, batch=min(batch, len(mine)), ring=ring,
+                                  force_collective=force_collective)
+                render_sharded.last_stats = g.stats          # (for tests / the bench line)
                 if frames_in_flight > 1 and first.is_cuda:
                     streams = [torch.cuda.Stream(device=first.device) for _ in range(int(frames_in_flight))]
                     for st in streams:

@@ -174,3 +174,44 @@ def test_bench_launches_its_own_ranks_selftest():
     from street_crafter_amd.dist import launch_ranks
     code = "import os,sys,time; sys.exit(7) if os.environ['RANK']=='1' else time.sleep(60)"
     assert launch_ranks([sys.executable, "-c", code], 2) == 7
+
+
+def _worker_world1_forced(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        g = FrameGatherer((12, 20, 3), "cpu", batch=3, ring=2, force_collective=True)
+        for r in range(10):                       # 3 full batches + a tail of 1; the third batch reuses buffer 0
+            if r % 2:
+                g.slot(r).copy_(_fake_frame(r))
+                g.submit(r)
+            else:
+                g.submit(r, _fake_frame(r))
+        out = g.drain()
+        same = len(out) == 10 and all(torch.equal(fr, _fake_frame(i)) for i, fr in enumerate(out))
+        frames = render_sharded(7, _fake_frame, batch=2, ring=2, force_collective=True)
+        same2 = len(frames) == 7 and all(torch.equal(fr, _fake_frame(i)) for i, fr in enumerate(frames))
+        q.put((same, g.stats["gathers"], same2, render_sharded.last_stats["gathers"]))
+        plain = FrameGatherer((12, 20, 3), "cpu", batch=3)          # the default at world 1: no collective at all
+        plain.submit(0, _fake_frame(0))
+        plain.drain()
+        q.put(plain.stats["gathers"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collective_sends_a_world_of_one_through_the_real_ring():
+    """FrameGatherer(force_collective=True): the staging ring + async gather run even when there is one rank (what
+    tests/rccl_world1.py does with backend nccl on the GPU box); without the flag a world of one issues none.
+    Without a process group the flag is refused."""
+    with pytest.raises(RuntimeError, match="init_process_group"):
+        FrameGatherer((4, 4, 3), "cpu", force_collective=True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1_forced, args=(_free_port(), q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == (True, 4, True, 4)
+    assert q.get(timeout=5) == 0
