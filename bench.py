@@ -67,7 +67,14 @@ def parse(argv=None):
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary measurement (keeps rocprof profiles of the headline clean)")
     ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: single_stream,two_in_flight,fused,"
-                                               "two_pass,street,train")
+                                               "two_pass,street,train,variants,knn,cpu_python,forced_gather")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N = 1 only: initialise RCCL (init_process_group('nccl', world_size=1)) and send the headline's "
+                         "frames through the REAL gather ring (FrameGatherer(force_collective=True)) instead of the "
+                         "world == 1 short cut")
+    ap.add_argument("--cpu-python-frames", type=int, default=1,
+                    help="timed frames of the pure-numpy oracle at S-100k for `cpu_baseline_python` (27 s each; "
+                         "BASELINE.md section 2's protocol is 1 warm-up + 3: pass 3 and a warm-up frame is added)")
     ap.add_argument("--scene-ply", default=None,
                     help="render a scene file in the reference's point_cloud.ply layout instead of S-<n>")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -167,6 +174,102 @@ def cpu_baseline(scene, cam, W, H, hip_frame_fn, budget_s=30.0):
     return base, parity
 
 
+def cpu_baseline_python(W, H, frames=1, n=100_000):
+    """BASELINE.md section 2's stated baseline: the pure-Python (numpy) oracle, oracle/gsplat_oracle.py, on S-100k at
+    full resolution on the GPU box's host (numpy's elementwise kernels run on ONE core).  `frames` timed frames
+    (+ 1 warm-up frame when frames >= 3: the BASELINE.md protocol; the default single frame keeps the bench run
+    short: a frame takes ~27 s)."""
+    from oracle import gsplat_oracle as O          # baseline only
+    from street_crafter_amd.scenes import make_camera, make_scene
+    sc = make_scene(n)
+    cam = make_camera(W, H, 2050.0 * W / 1920.0, 2050.0 * W / 1920.0)
+    a = (sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), sc.opacities.numpy(), sc.sh.numpy(),
+         cam.viewmat.numpy(), cam.K.numpy(), W, H, sc.sh_degree)
+    kw = dict(near_plane=cam.znear, far_plane=cam.zfar)
+    warm = 1 if frames >= 3 else 0
+    times, n_is = [], 0
+    for k in range(warm + frames):
+        t0 = time.perf_counter()
+        r = O.render_frame(*a, **kw)
+        dt = time.perf_counter() - t0
+        n_is = int(r["flatten_ids"].size)
+        if k >= warm:
+            times.append(dt)
+    med = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/gsplat_oracle.py (pure numpy, vectorised per tile; numpy's elementwise loops use one "
+                      f"core) on S-{n // 1000}k {W}x{H} (I={n_is}): {warm} warm-up + {frames} timed frame(s), value = "
+                      f"1 / median ({med:.1f} s)",
+            "frame_seconds": times, "host_cpus": os.cpu_count(),
+            "what": "the pure-Python/CPU rasterizer BASELINE.md section 2 and north_star name; `cpu_baseline` beside it "
+                    "is the stronger C + OpenMP port on the headline's own S-1M frame"}
+
+
+def pmc_traffic_entry(traffic_json, op, key, kernel_symbol):
+    """HBM bytes per launch of `op` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or
+    (None, reason) when the file has no such entry or was recorded for ANOTHER kernel symbol (it goes stale silently
+    when a kernel changes: the symbol the counters were collected on is stored beside them and must match)."""
+    val = traffic_json.get(op, {}).get(key)
+    if val is None:
+        return None, f"profiles/pmc_traffic.json has no entry {op}/{key}"
+    recorded = traffic_json.get("_kernels", {}).get(key, {}).get(op)
+    if not recorded:
+        return None, "profiles/pmc_traffic.json does not say which kernel symbol its counters were collected on (stale file)"
+    want = kernel_symbol.replace(" ", "")
+    if not any(want in r.replace(" ", "") for r in recorded):
+        return None, (f"profiles/pmc_traffic.json was recorded on {recorded}, this build launches {kernel_symbol}: "
+                      "re-run tools/pmc_run.sh")
+    return val, ("profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel symbol from separate rocprofv3 "
+                 "--pmc passes (committed; not re-measured in this run)")
+
+
+KNN_BYTES_PER_POINT = 104
+KNN_BYTES_WHAT = ("12 (bbox pass reads the points) + 24 (Morton pass: 12 in, 8-B key + 4-B id out) + 24 (sort counted as "
+                  "ONE read + one write of the 12-B pairs, as SURVEY 8d counts the tile sort) + 28 (gather into curve "
+                  "order: id 4 + point 12 in, point 12 out) + 16 (search: own point 12 in, result 4 out; box AABBs are "
+                  "24 B per 1024 points) = 104 B per point")
+
+
+def knn_line(dev, n=1_000_000, reps=7):
+    """a14 (gaussian_model.py:65-66): simple_knn._C.distCUDA2 on n uniform points and on n street-LiDAR-shaped points
+    (the foreground of scenes.make_street_scene: ground plane, facades, clutter), HIP events around the call on
+    the current stream, median of `reps` after 2 warm-ups."""
+    import torch
+    from simple_knn._C import distCUDA2
+    from street_crafter_amd.scenes import make_street_scene
+    g = torch.Generator().manual_seed(20250404)
+    clouds = {"uniform": (torch.rand(n, 3, generator=g) * 100.0).to(dev),
+              "street_lidar_shaped": make_street_scene(n)[0].means.to(dev).contiguous()}
+    out = {"n_points": n, "algorithmic_bytes": KNN_BYTES_PER_POINT * n, "algorithmic_bytes_is": KNN_BYTES_WHAT,
+           "kernels": "knn_box_minmax x2, knn_reduce_boxes, knn_morton, radix sort (4 passes over the 30-bit code), "
+                      "knn_mean_dist", "call_site": "street_gaussian/models/gaussian_model.py:65-66"}
+    for name, pts in clouds.items():
+        for _ in range(2):
+            distCUDA2(pts)
+        ms = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            distCUDA2(pts)
+            b.record()
+            b.synchronize()
+            ms.append(a.elapsed_time(b))
+        med = sorted(ms)[len(ms) // 2]
+        out[name] = {"ms": med, "points_per_s": n / (med * 1e-3), "gb_per_s": KNN_BYTES_PER_POINT * n / (med * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": KNN_BYTES_PER_POINT * n / (med * 1e-3) / HBM_PEAK}
+    out["what"] = ("init-time operator (once per sub-model); bound by the pruned candidate scan (distance evaluations "
+                   "per point), not by bandwidth: the clustered cloud walks more boxes per point")
+    return out
+
+
+def raster_bwd_algorithmic_bytes(I, P):
+    """Backward of rasterize_to_pixels at the operator boundary, by analogy with SURVEY 8(d)'s forward figure: the
+    replayed gather (44 B per intersection: id 4 + xy 8 + opacity 4 + conic 12 + colour 16), ONE set of gradient
+    atomics per (Gaussian, tile) (v_means2d 8 + absgrad 8 + v_conics 12 + v_colors 16 + v_opacities 4 = 48 B), and
+    28 B per pixel in (v_render_colors 16, v_render_alphas 4, render_alphas 4, last_ids 4)."""
+    return (44 + 48) * I + 28 * P
+
+
 # ---------------------------------------------------------------------------------------------
 def launch_self(args) -> int:
     """--gpus N > 1 without a launcher: start the N ranks from here.  This parent never initialises the
@@ -193,9 +296,43 @@ def main():
     run_rank(args)
 
 
+def init_world1(dev):
+    """init_process_group("nccl", world_size=1): the same call a rank of an N > 1 job makes, on the one GPU here."""
+    import torch.distributed as dist
+    from street_crafter_amd.dist import free_port
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+
+
+_REAL_STDOUT = None
+
+
+def emit(line: dict):
+    """The ONE JSON line of rank 0, written to the process's original stdout."""
+    data = (json.dumps(line) + "\n").encode()
+    if _REAL_STDOUT is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_REAL_STDOUT, data)
+
+
 def run_rank(args):
     import torch
     import torch.distributed as dist
+
+    # RCCL prints a version banner ("RCCL version : ...", five lines) to STDOUT when its first communicator is
+    # created (seen on the one-GPU box as soon as the forced gather initialised it).  Rank 0's stdout must carry ONE
+    # JSON line: from here on file descriptor 1 points at stderr, and the line is written to the saved descriptor.
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -229,6 +366,8 @@ def run_rank(args):
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world)
+        elif args.force_gather:
+            init_world1(dev)
 
     from street_crafter_amd.dist import FrameGatherer, to_uint8_frame
     W, H = args.width, args.height
@@ -238,7 +377,8 @@ def run_rank(args):
     n_streams = 1 if selftest else max(1, args.frames_in_flight)
     skip = set(x for x in args.skip.split(",") if x)
     if args.headline_only:
-        skip |= {"single_stream", "two_in_flight", "fused", "two_pass", "street", "train"}
+        skip |= {"single_stream", "two_in_flight", "fused", "two_pass", "street", "train", "variants", "knn", "cpu_python",
+                 "forced_gather"}
 
     if selftest:
         W, H = 64, 48
@@ -277,7 +417,8 @@ def run_rank(args):
                 to_uint8_frame(o["rgb"], out=out)
             return o
 
-    gatherer = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch)
+    gatherer = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch,
+                             force_collective=bool(args.force_gather and world == 1 and not selftest))
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if (not selftest and n_streams > 1) else None
     def recorder():
         return {"events": {}, "n_isects": [], "frame_ev": [], "probe_ev": []}
@@ -383,7 +524,7 @@ def run_rank(args):
             line.update({"data": "selftest-cpu (stand-in frames over gloo: launcher / sharding / gather plumbing only)",
                          "config": {"workload": "selftest", "parallelism": f"frames x{world}"},
                          "roofline": None, "selftest": True})
-            print(json.dumps(line), flush=True)
+            emit(line)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -396,8 +537,8 @@ def run_rank(args):
         from harness.caller import render_novel_view_u8
         op1 = scene.opacities[:, 0].contiguous()
 
-        def fresh():
-            return FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch)
+        def fresh(shape=None):
+            return FrameGatherer(shape or (H, W, 3), dev, dst=0, batch=args.gather_batch)
 
         def fused_into(s, out, events=None, intermediates=False):
             cam = cams[s]
@@ -408,8 +549,8 @@ def run_rank(args):
                                          rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
                 to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1), out=out)
 
-        def measure(step_fn, n_str, what, compare=None, rec=None):
-            el, _, fr = timed_run(step_fn, fresh(), n_str, rec)
+        def measure(step_fn, n_str, what, compare=None, rec=None, shape=None):
+            el, _, fr = timed_run(step_fn, fresh(shape), n_str, rec)
             d = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
                  "frames_in_flight": n_str, "what": what}
             if compare is not None:
@@ -488,12 +629,72 @@ def run_rank(args):
                     d["isect_route"] = "radix (bucketed path returned SC_EUNSUPPORTED)"
                 secondary["street_scene"][f"n{n_st}"] = d
                 del fg, sky
+        if "variants" not in skip and not args.scene_ply:
+            # BASELINE config 1 (100 k Gaussians, configs/waymo_val_121.yaml:18 sh_degree 1) and SURVEY 8(d)'s "variants
+            # to also report": K = 16 (sh_degree 3, the library default: street_gaussian/config/config.py:100) and the
+            # reference's train / render resolution 1600 x 1066 (utils/camera_utils.py:150-152) -- same caller sequence,
+            # same timing as the headline (two frames in flight) and one frame at a time beside it
+            secondary["variants"] = {}
+            for vname, vn, vw, vh, vdeg, vwhat in (
+                    ("s100k", 100_000, W, H, args.sh_degree, "BASELINE config 1: S-100k static forward raster"),
+                    ("k16", args.n_gauss, W, H, 3, "SURVEY 8d variant: sh_degree 3 (K = 16 SH bases)"),
+                    ("w1600", args.n_gauss, 1600, (1600 * H) // W, args.sh_degree,
+                     "SURVEY 8d variant: the reference's render resolution (camera_utils.py:150-152: 1600 px wide, "
+                     "int() of the scaled height)")):
+                sc_v = scene if (vn == args.n_gauss and vdeg == args.sh_degree) else make_scene(vn, sh_degree=vdeg).to(dev)
+                cams_v = [frame_camera(s, vw, vh).to(dev) for s in range(total_steps)]
+                rec_v = recorder()
+
+                def variant_into(s, out, events=None, intermediates=False, sc_v=sc_v, cams_v=cams_v):
+                    with torch.no_grad():
+                        o = render_gaussians(sc_v, cams_v[s], stage_events=events, return_intermediates=intermediates)
+                        to_uint8_frame(o["rgb"], out=out)
+                    return o
+
+                d2, _ = measure(variant_into, 2, f"{vwhat}, {vn} Gaussians, {vw}x{vh}, sh_degree {vdeg}; caller "
+                                "sequence -> uint8 frame, two frames in flight (the headline's timing)", rec=rec_v,
+                                shape=(vh, vw, 3))
+                d1, _ = measure(variant_into, 1, "same, one frame in flight", shape=(vh, vw, 3))
+                torch.cuda.synchronize(dev)
+                Kv, Pv, Tv = (vdeg + 1) ** 2, vw * vh, math.ceil(vw / 16) * math.ceil(vh / 16)
+                I_v = sum(rec_v["n_isects"]) / max(len(rec_v["n_isects"]), 1)
+                b_v = algorithmic_bytes(vn, int(I_v), vw, vh, 16, Kv)
+                d2["single_stream"] = {"value": d1["value"], "ms_per_step": d1["ms_per_step"], "frames_in_flight": 1,
+                                       "frac_of_hbm_roofline_wall": d1["value"] / (HBM_PEAK / b_v)}
+                d2["n_isects_mean"] = I_v
+                d2["frame_roofline"] = {"algorithmic_bytes_per_frame": b_v, "hbm_bound_fps_per_gpu": HBM_PEAK / b_v,
+                                        "frac_of_hbm_roofline_wall": d2["value"] / (HBM_PEAK / b_v),
+                                        "per_gaussian_bytes": 72 + 25 + 12 * Kv + 52}
+                d2["stage_ms"] = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in rec_v["events"].items()}
+                d2["stage_ms_is"] = "mean over the probe frames (every 8th timed frame), two frames in flight"
+                secondary["variants"][vname] = d2
+                del sc_v, cams_v
+        if "knn" not in skip:
+            secondary["knn"] = knn_line(dev)
+        if "forced_gather" not in skip and not args.force_gather:
+            # the RCCL transport on the one GPU of this box: a world of ONE through the real staging ring + async
+            # dist.gather (VERDICT r2 missing 1).  Not a scaling number -- there is none until an 8-GPU node runs this.
+            try:
+                init_world1(dev)
+                gf = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch, force_collective=True)
+                el, _, fr = timed_run(render_into, gf, n_streams)
+                secondary["forced_gather_world1"] = {
+                    "value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
+                    "frames_in_flight": n_streams, "backend": dist.get_backend(), "collectives": gf.stats["gathers"],
+                    "frames_per_collective": gf.batch,
+                    "frames_identical_to_headline": bool(all(torch.equal(a, b) for a, b in zip(frames, fr))),
+                    "what": "the headline loop with init_process_group('nccl', world_size=1) and the world == 1 short cut of "
+                            "the gatherer disabled: every frame goes through the staging ring and an async dist.gather on "
+                            "RCCL's stream (at one rank the collective is a device copy; no bytes cross xGMI)"}
+                del fr, gf
+            except Exception as e:          # noqa: BLE001  (a box whose RCCL cannot initialise must not cost the bench line)
+                secondary["forced_gather_world1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if "train" not in skip and not args.scene_ply:
             # SURVEY 8(d) secondary: forward + backward steps/s at the reference's training resolution
             # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
             # groups requiring grad, absgrad on -- the shape of BASELINE config 2.
             from street_crafter_amd.scenes import make_camera
-            tw_, th_ = 1600, int(round(1600 * H / W))
+            tw_, th_ = 1600, (1600 * H) // W          # camera_utils.py:150-152: int(orig_h * 1600 / orig_w) = 1066
             tcam = make_camera(tw_, th_, 2050.0 * tw_ / 1920.0, 2050.0 * tw_ / 1920.0).to(dev)
             tscene = make_scene(args.n_gauss, sh_degree=args.sh_degree).to(dev)
             tparams = (tscene.means, tscene.quats, tscene.scales, tscene.opacities, tscene.sh)
@@ -501,25 +702,63 @@ def run_rank(args):
                 t.requires_grad_(True)
             target = torch.rand(3, th_, tw_, device=dev)
 
-            def train_step():
+            def train_step(fwd_ev=None, bwd_ev=None):
                 for t in tparams:
                     t.grad = None
-                out = render_gaussians(tscene, tcam, mode="train")
-                ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
+                out = render_gaussians(tscene, tcam, mode="train", stage_events=fwd_ev, return_intermediates=fwd_ev is not None)
+                prev = rendering.set_backward_probe(bwd_ev)
+                try:
+                    ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
+                finally:
+                    rendering.set_backward_probe(prev)
+                return out
 
             for _ in range(3):
                 train_step()
             torch.cuda.synchronize()
+            ms0 = torch.cuda.memory_stats(dev)
             t1 = time.perf_counter()
             n_train = min(args.steps, 20)
+            host_t = []
             for _ in range(n_train):
+                h0 = time.perf_counter()
                 train_step()
+                host_t.append(time.perf_counter() - h0)
+            t_enq = time.perf_counter() - t1
             torch.cuda.synchronize()
             el = time.perf_counter() - t1
+            if args.stage_times:
+                ms1 = torch.cuda.memory_stats(dev)
+                import gc
+                print("train: host enqueue per step (ms)", [round(x * 1e3, 2) for x in host_t], "enqueue total", round(t_enq * 1e3, 2),
+                      "wall", round(el * 1e3, 2), "device mallocs during the timed steps",
+                      ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0), "alloc retries",
+                      ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0), "reserved GB",
+                      ms1.get("reserved_bytes.all.current", 0) / 1e9, "gc counts", gc.get_count(), "gc objects", len(gc.get_objects()),
+                      file=sys.stderr)
+            # probe steps AFTER the timed ones: HIP events around every forward operator and every backward operator
+            fwd_ev, bwd_ev = {}, {}
+            for _ in range(5):
+                o_t = train_step(fwd_ev, bwd_ev)
+            torch.cuda.synchronize()
+            I_t = int(o_t["_isect_ids"].numel())
+            P_t = tw_ * th_
+            med = lambda v: sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2]      # noqa: E731
+            st_ms = {k: med(v) for k, v in fwd_ev.items()}
+            st_ms.update({k: med(v) for k, v in bwd_ev.items()})
+            bwd_ms = st_ms.get("rasterize_to_pixels_bwd")
+            bwd_bytes = raster_bwd_algorithmic_bytes(I_t, P_t)
+            tkey = f"train_n{args.n_gauss}_{tw_}x{th_}"
             secondary["train_fwd_bwd"] = {
                 "value": n_train / el, "unit": "steps/s", "ms_per_step": el / n_train * 1e3,
-                "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad"}
-            del tscene, tparams, target
+                "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad "
+                        "(train.py:236; BASELINE config 2's shape)",
+                "n_isects": I_t, "stage_ms": st_ms,
+                "stage_ms_is": "median of 5 probe steps after the timed ones: HIP events around every forward operator "
+                               "(harness) and every backward operator (rendering.set_backward_probe), kernels running alone",
+                "device_ms_operators_sum": sum(st_ms.values()),
+                "_traffic_key": tkey, "_bwd_bytes": bwd_bytes, "_bwd_ms": bwd_ms, "_pairs": 256 * I_t}
+            del tscene, tparams, target, o_t
 
     # ---- per-operator device time from the probe frames' HIP events ----------------------------------------
     torch.cuda.synchronize(dev)
@@ -531,6 +770,9 @@ def run_rank(args):
             traffic_json = json.load(open(tj))
         except Exception:
             traffic_json = {}
+
+    def pmc_traffic(op, key, kernel_symbol):
+        return pmc_traffic_entry(traffic_json, op, key, kernel_symbol)
 
     def kernel_report(rec, in_flight):
         """stage_ms / operators / roofline of one run's probe frames."""
@@ -547,13 +789,14 @@ def run_rank(args):
         dom = "rasterize_to_pixels"
         dom_ms = stage[dom]
         dom_bytes = stage_algorithmic_bytes(dom, args.n_gauss, I_m, P, T, K)
-        traffic = traffic_json.get(dom, {}).get(f"n{args.n_gauss}")
+        traffic, tsrc = pmc_traffic(dom, f"n{args.n_gauss}", OPERATOR_KERNEL[dom])
+        ratio = None if traffic is None else traffic / dom_bytes
         roof = {"bound": "hbm", "kernel": OPERATOR_KERNEL[dom],
                 "achieved": dom_bytes / (dom_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": dom_bytes / (dom_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
-                "traffic_source": None if traffic is None else
-                ("profiles/pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc "
-                 "passes (committed; not re-measured in this run)"),
+                "traffic_source": tsrc,
+                "traffic_over_algorithmic": ratio,
+                "real_hbm_gb_per_s": None if traffic is None else traffic / (dom_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": dom_ms,
                 "launches_timed": len(ev.get(dom, [])), "frames_in_flight": in_flight,
                 "how": "HIP events around the rasterize_to_pixels operator (= this one kernel launch) on the probe "
@@ -563,9 +806,11 @@ def run_rank(args):
                        "; algorithmic bytes = 44 B x I (id + xy + opacity + conic + colour gathered per intersection) "
                        "+ 24 B x P (SURVEY 8d)",
                 "note": "an HBM-EQUIVALENT rate: the kernel is VALU-bound, not bandwidth-bound.  Tiles terminate after "
-                        "~12 % of their lists, so the bytes it really moves are ~0.12 of the algorithmic figure "
-                        "(`traffic`); its floor is VALU issue: ~58 VALU instructions incl. 4 v_exp_f32 per blended "
-                        "splat per tile, ~94 us at S-1M (DESIGN.md section 4)"}
+                        "~12 % of their lists, so the bytes it really moves are " +
+                        ("unknown here (no valid PMC record)" if ratio is None else
+                         f"{ratio:.3f} of the algorithmic figure (`traffic` / `algorithmic_bytes_per_launch`), i.e. "
+                         f"{traffic / (dom_ms * 1e-3) / HBM_PEAK:.2f} of the HBM peak") +
+                        "; its floor is VALU issue (DESIGN.md section 4)"}
         return stage, ops, roof, I_m
 
     stage_ms, operators, roofline, I_mean = kernel_report(main_rec, n_streams)
@@ -609,7 +854,28 @@ def run_rank(args):
             "probe_frame_ms_device": {**(percentiles([a.elapsed_time(b) for a, b in main_rec["probe_ev"]]) or {}),
                                       "what": "the probe frames (10 more event pairs and the intermediates kept)"},
         })
+        tr = secondary.get("train_fwd_bwd")
+        if tr is not None and "_bwd_ms" in tr:
+            bwd_ms, bwd_bytes, tkey, pairs = tr.pop("_bwd_ms"), tr.pop("_bwd_bytes"), tr.pop("_traffic_key"), tr.pop("_pairs")
+            ksym = "raster_bwd_wave_kernel<4>"
+            if bwd_ms:
+                traffic, tsrc = pmc_traffic("rasterize_to_pixels_bwd", tkey, ksym)
+                tr["roofline"] = {
+                    "bound": "hbm", "kernel": ksym, "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / HBM_PEAK, "traffic": traffic,
+                    "traffic_source": tsrc, "traffic_over_algorithmic": None if traffic is None else traffic / bwd_bytes,
+                    "algorithmic_bytes_per_launch": bwd_bytes, "avg_launch_ms": bwd_ms, "launches_timed": 5,
+                    "valu_pair_bound": pairs,
+                    "how": "HIP events around sc_rasterize_bwd (= this one kernel launch) inside autograd's backward, on "
+                           "5 probe steps after the timed ones (rendering.set_backward_probe); algorithmic bytes = 92 B x I "
+                           "(replayed 44-B gather + one 48-B set of gradient atomics per (Gaussian, tile)) + 28 B x P "
+                           "(DESIGN.md section 4)",
+                    "note": "HBM-EQUIVALENT like the forward's: the replay walks only the part of each list the forward "
+                            "blended, and its cost is VALU (the same pairs with ~2.5x the instructions) plus one 12-lane "
+                            "atomic per kept splat and tile"}
         line.update(secondary)
+        if world == 1 and "cpu_python" not in skip and not args.no_cpu_baseline:
+            line["cpu_baseline_python"] = cpu_baseline_python(W, H, frames=max(1, args.cpu_python_frames))
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             def hip_frame():
                 with torch.no_grad():
@@ -620,9 +886,10 @@ def run_rank(args):
             line["cpu_baseline"], line["parity"] = cpu_baseline(scene, cams[0], W, H, hip_frame)
         if args.stage_times:
             print(json.dumps(stage_ms, indent=1), file=sys.stderr)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
+        emit(line)
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

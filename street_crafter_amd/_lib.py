@@ -118,6 +118,43 @@ def load():
     return lib
 
 
+FAST_PATH = os.path.join(_HERE, "lib", "_sc_fast.so")
+_fast = None
+_fast_enabled = True
+
+
+def fast():
+    """The compiled binding layer (csrc/binding.cpp: one call per operator validates the tensors, allocates every
+    output / workspace through torch's caching allocator and calls the same C-ABI entry point as the ctypes table
+    above), or None when it is switched off (set_fast_binding(False), or the diagnostic build is selected: the binding
+    is linked against the shipped library).  A missing binding is an ImportError, never a silent fallback."""
+    global _fast
+    if not _fast_enabled or _path != LIB_PATH:
+        return None
+    if _fast is None:
+        load()
+        if not os.path.exists(FAST_PATH):
+            raise ImportError(f"street_crafter_amd: binding layer not built ({FAST_PATH} missing). "
+                              "Build it with `python -m street_crafter_amd.build`.")
+        import importlib.util
+        import torch  # noqa: F401  (libtorch must be loaded before the extension)
+        spec = importlib.util.spec_from_file_location("_sc_fast", FAST_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.abi_version().encode() != load().sc_version():
+            raise ImportError("street_crafter_amd: _sc_fast.so and libstreet_crafter_hip.so are different builds")
+        _fast = mod
+    return _fast
+
+
+def set_fast_binding(enabled: bool) -> bool:
+    """A/B switch between the compiled binding layer (default) and the ctypes table; same C ABI, same kernels, same
+    results.  Returns the previous setting."""
+    global _fast_enabled
+    prev, _fast_enabled = _fast_enabled, bool(enabled)
+    return prev
+
+
 def check(code: int, what: str):
     if code != 0:
         msg = load().sc_error_string(int(code)).decode()

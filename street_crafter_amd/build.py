@@ -24,6 +24,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "libstreet_crafter_hip.so")
 LIB_DIAG = os.path.join(LIBDIR, "libstreet_crafter_hip_diag.so")
+BINDING = os.path.join(LIBDIR, "_sc_fast.so")          # compiled Python <-> C-ABI binding layer (csrc/binding.cpp)
 ARCH = "gfx950"
 
 SOURCES = ["capi.hip", "projection.hip", "isect.hip", "isect_bin.hip", "radix_sort.hip", "sh.hip",
@@ -87,8 +88,36 @@ def build(force=False, verbose=False, jobs=None, diag=False):
     return lib
 
 
+def build_binding(force=False, verbose=False):
+    """The compiled binding layer (csrc/binding.cpp -> lib/_sc_fast.so): host-only C++ (g++), built against torch's
+    headers for tensor allocation and against libstreet_crafter_hip.so for the C ABI it calls.  ~1 minute."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "binding.cpp")
+    deps = [src, os.path.join(HERE, "..", "include", "street_crafter_amd.h")]
+    if not os.path.exists(LIB):
+        raise RuntimeError("build the HIP library first")
+    if not force and not _stale(BINDING, deps):
+        return BINDING
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", BINDING,
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_sc_fast",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations",
+           *[f"-I{i}" for i in ce.include_paths()], f"-I{sysconfig.get_paths()['include']}",
+           f"-L{LIBDIR}", "-lstreet_crafter_hip", f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python",
+           "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"binding build failed:\n{r.stdout}\n{r.stderr[-4000:]}")
+    return BINDING
+
+
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    print("built", build_binding(force="--force" in sys.argv, verbose=True))
     if "--diag" in sys.argv:
         print("built", build(force="--force" in sys.argv, verbose=True, diag=True))

@@ -1,0 +1,235 @@
+// Host-side binding layer: Python <-> the C ABI of include/street_crafter_amd.h, compiled (g++, no device code).
+//
+// WHY.  The operators keep the reference's Python signatures (gsplat.rendering.*, called one by one from
+// street_gaussian/models/street_gaussian_renderer.py:219-280), so every frame crosses Python -> native five times.
+// Through ctypes a crossing costs ~6-8 us of argument conversion, and every output / workspace tensor a separate
+// ~3-4 us torch.empty from Python: ~150 us of host time per frame (tools/exp_host.py), which is what bounds small
+// scenes (S-100k: 0.24-0.30 ms per frame, all of it host) and makes the training step's rate depend on how busy the
+// box's host is (BENCH_r02: 786 steps/s on the driver's box, 1060 on a quiet one, for 0.78 ms of kernels).
+// Here one call per operator validates its tensors, allocates ALL of its outputs and scratch through torch's
+// caching allocator (at::empty: stream-ordered reuse, no hipMalloc) and calls the SAME C-ABI entry point.  Nothing
+// else moves: the C ABI stays the boundary, kernels and results are untouched, autograd wiring stays in
+// rendering.py.  torch is used for what it is here for: device memory.
+//
+// The library's entry points are resolved at link time (libstreet_crafter_hip.so, rpath $ORIGIN).  Streams arrive as
+// the raw hipStream_t value (torch._C._cuda_getCurrentRawStream), so no HIP header is needed.
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <tuple>
+#include <vector>
+
+#include "../../include/street_crafter_amd.h"
+
+namespace {
+
+using at::Tensor;
+using OptT = c10::optional<Tensor>;
+
+inline sc_stream_t S(int64_t s) { return reinterpret_cast<sc_stream_t>(static_cast<uintptr_t>(s)); }
+
+inline void req(const Tensor& t, at::ScalarType dt, const char* name) {
+    TORCH_CHECK(t.is_cuda(), name, " must live on a HIP device (got ", t.device(), "); street_crafter_amd has no CPU path");
+    TORCH_CHECK(t.scalar_type() == dt, name, " must be ", dt, ", got ", t.scalar_type());
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+}
+inline const float* fp(const Tensor& t) { return static_cast<const float*>(t.data_ptr()); }
+inline float* fpw(const Tensor& t) { return static_cast<float*>(t.data_ptr()); }
+inline const float* fpo(const OptT& t) { return t.has_value() ? static_cast<const float*>(t->data_ptr()) : nullptr; }
+inline const int32_t* ip(const Tensor& t) { return static_cast<const int32_t*>(t.data_ptr()); }
+inline at::TensorOptions f32(const Tensor& like) { return like.options().dtype(at::kFloat); }
+inline at::TensorOptions i32(const Tensor& like) { return like.options().dtype(at::kInt); }
+inline at::TensorOptions u8(const Tensor& like) { return like.options().dtype(at::kByte); }
+
+// ---- a1 ---------------------------------------------------------------------------------------------------
+// -> (rc, radii, means2d, depths, conics, compensations | None)
+py::tuple projection_fwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, double near_plane,
+                         double far_plane, double radius_clip, bool calc_comp, int64_t stream) {
+    req(means, at::kFloat, "means"); req(quats, at::kFloat, "quats"); req(scales, at::kFloat, "scales");
+    req(viewmats, at::kFloat, "viewmats"); req(Ks, at::kFloat, "Ks");
+    const int64_t C = viewmats.size(0), N = means.size(0);
+    Tensor radii = at::empty({C, N}, i32(means));
+    Tensor means2d = at::empty({C, N, 2}, f32(means));
+    Tensor depths = at::empty({C, N}, f32(means));
+    Tensor conics = at::empty({C, N, 3}, f32(means));
+    OptT comps;
+    if (calc_comp) comps = at::empty({C, N}, f32(means));
+    const int rc = sc_projection_fwd(fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)C, (int)N, (int)width,
+                                     (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip,
+                                     static_cast<int32_t*>(radii.data_ptr()), fpw(means2d), fpw(depths), fpw(conics),
+                                     comps ? fpw(*comps) : nullptr, S(stream));
+    return py::make_tuple(rc, radii, means2d, depths, conics, comps);
+}
+
+// -> (rc, v_means, v_quats, v_scales)
+py::tuple projection_bwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, const Tensor& radii,
+                         const Tensor& conics, const OptT& comps, const Tensor& v_means2d, const Tensor& v_depths,
+                         const Tensor& v_conics, const OptT& v_comps, int64_t stream) {
+    req(v_means2d, at::kFloat, "v_means2d"); req(v_depths, at::kFloat, "v_depths"); req(v_conics, at::kFloat, "v_conics");
+    if (v_comps) req(*v_comps, at::kFloat, "v_compensations");
+    const int64_t C = viewmats.size(0), N = means.size(0);
+    Tensor v_means = at::empty_like(means), v_quats = at::empty_like(quats), v_scales = at::empty_like(scales);
+    const int rc = sc_projection_bwd(fp(means), fp(quats), fp(scales), fp(viewmats), fp(Ks), (int)C, (int)N, (int)width,
+                                     (int)height, (float)eps2d, ip(radii), fp(conics), fpo(comps), fp(v_means2d),
+                                     fp(v_depths), fp(v_conics), fpo(v_comps), fpw(v_means), fpw(v_quats),
+                                     fpw(v_scales), S(stream));
+    return py::make_tuple(rc, v_means, v_quats, v_scales);
+}
+
+// ---- a3 (tile-bucketed route) -------------------------------------------------------------------------------
+// count phase: allocates tiles_per_gauss, isect_offsets, meta_dev, the count workspace and (want_order) the dispatch
+// list.  -> (rc, tiles_per_gauss, offsets, meta_dev, count_ws, tile_order | None)
+py::tuple isect_bin_count(const Tensor& means2d, const Tensor& radii, const Tensor& depths, int64_t tile_size,
+                          int64_t tile_width, int64_t tile_height, const OptT& tile_work, const OptT& viewmats,
+                          const OptT& registry, bool want_order, int64_t meta_host_ptr, int64_t seq, int64_t stream) {
+    req(means2d, at::kFloat, "means2d"); req(radii, at::kInt, "radii"); req(depths, at::kFloat, "depths");
+    const int64_t C = radii.size(0), N = radii.size(1);
+    Tensor tpg = at::empty({C, N}, i32(means2d));
+    Tensor offsets = at::empty({C, tile_height, tile_width}, i32(means2d));
+    Tensor meta_dev = at::empty({4}, means2d.options().dtype(at::kLong));
+    size_t wsb = sc_isect_bin_workspace_bytes(C * N, (int)C, (int)tile_width, (int)tile_height, -1);
+    if (wsb < 256) wsb = 256;
+    Tensor ws0 = at::empty({(int64_t)wsb}, u8(means2d));
+    OptT order;
+    if (want_order) order = at::empty({(int64_t)sc_tile_order_len((int)(C * tile_width * tile_height))}, i32(means2d));
+    const int rc = sc_isect_bin_count(
+        fp(means2d), ip(radii), fp(depths), (int)C, (int)N, (int)tile_size, (int)tile_width, (int)tile_height,
+        static_cast<int32_t*>(tpg.data_ptr()), static_cast<int32_t*>(offsets.data_ptr()),
+        static_cast<int64_t*>(meta_dev.data_ptr()), reinterpret_cast<int64_t*>(static_cast<uintptr_t>(meta_host_ptr)), seq,
+        ws0.data_ptr(), wsb, (want_order && tile_work) ? ip(*tile_work) : nullptr, viewmats ? fp(*viewmats) : nullptr,
+        registry ? static_cast<int32_t*>(registry->data_ptr()) : nullptr,
+        order ? static_cast<int32_t*>(order->data_ptr()) : nullptr, S(stream));
+    return py::make_tuple(rc, tpg, offsets, meta_dev, ws0, order);
+}
+
+// sort phase: allocates flatten_ids (+ isect_ids when want_ids) for `capacity` elements and the sort workspace (freed
+// on return: the caching allocator reuses a block only for LATER work of the same stream).
+// -> (rc, isect_ids | None, flatten_ids)
+py::tuple isect_bin_sort(const Tensor& means2d, const Tensor& radii, const Tensor& depths, int64_t tile_size,
+                         int64_t tile_width, int64_t tile_height, const Tensor& offsets, const Tensor& meta_dev,
+                         const Tensor& ws0, int64_t capacity, int64_t rec_capacity, int64_t super_capacity, bool want_ids,
+                         int64_t stream) {
+    const int64_t C = radii.size(0), N = radii.size(1);
+    OptT ids;
+    if (want_ids) ids = at::empty({capacity}, means2d.options().dtype(at::kLong));
+    Tensor fids = at::empty({capacity}, i32(means2d));
+    size_t wsb = sc_isect_bin_workspace_bytes(C * N, (int)C, (int)tile_width, (int)tile_height, rec_capacity);
+    if (wsb < 256) wsb = 256;
+    Tensor ws = at::empty({(int64_t)wsb}, u8(means2d));
+    const int rc = sc_isect_bin_sort(fp(means2d), ip(radii), fp(depths), (int)C, (int)N, (int)tile_size, (int)tile_width,
+                                     (int)tile_height, ip(offsets), static_cast<const int64_t*>(meta_dev.data_ptr()),
+                                     ws0.data_ptr(), capacity, rec_capacity, super_capacity,
+                                     ids ? static_cast<int64_t*>(ids->data_ptr()) : nullptr,
+                                     static_cast<int32_t*>(fids.data_ptr()), ws.data_ptr(), wsb, S(stream));
+    return py::make_tuple(rc, ids, fids);
+}
+
+// host-side wait for the counts (the GIL is released: another host thread keeps launching)
+int wait_i64(int64_t addr, int64_t value, int64_t timeout_us) {
+    py::gil_scoped_release nogil;
+    return sc_wait_i64(reinterpret_cast<const int64_t*>(static_cast<uintptr_t>(addr)), value, timeout_us);
+}
+
+// ---- a6 ---------------------------------------------------------------------------------------------------
+py::tuple sh_fwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, int64_t stream) {
+    req(dirs, at::kFloat, "dirs"); req(coeffs, at::kFloat, "coeffs");
+    if (masks) req(*masks, at::kByte, "masks");
+    const int64_t M = dirs.numel() / 3, K = coeffs.size(-2);
+    Tensor colors = at::empty(dirs.sizes(), f32(dirs));
+    const int rc = sc_sh_fwd((int)degree, fp(dirs), fp(coeffs), masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr,
+                             M, (int)K, fpw(colors), S(stream));
+    return py::make_tuple(rc, colors);
+}
+
+py::tuple sh_bwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, const Tensor& v_colors,
+                 bool need_dirs, int64_t stream) {
+    req(v_colors, at::kFloat, "v_colors");
+    const int64_t M = dirs.numel() / 3, K = coeffs.size(-2);
+    Tensor v_coeffs = at::empty_like(coeffs);
+    OptT v_dirs;
+    if (need_dirs) v_dirs = at::empty_like(dirs);
+    const int rc = sc_sh_bwd((int)degree, fp(dirs), fp(coeffs), masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr,
+                             M, (int)K, fp(v_colors), fpw(v_coeffs), v_dirs ? fpw(*v_dirs) : nullptr, S(stream));
+    return py::make_tuple(rc, v_coeffs, v_dirs);
+}
+
+// ---- a9 / a11 ------------------------------------------------------------------------------------------------
+// -> (rc, render_colors, render_alphas, last_ids | None)
+py::tuple rasterize_fwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                        const Tensor& offsets, const Tensor& flatten_ids, bool want_last, const OptT& order,
+                        const OptT& work, int64_t stream) {
+    req(means2d, at::kFloat, "means2d"); req(conics, at::kFloat, "conics"); req(colors, at::kFloat, "colors");
+    req(opacities, at::kFloat, "opacities"); req(offsets, at::kInt, "isect_offsets"); req(flatten_ids, at::kInt, "flatten_ids");
+    const int64_t C = opacities.size(0), N = opacities.size(1), D = colors.size(-1);
+    const int64_t th = offsets.size(1), tw = offsets.size(2);
+    Tensor rc_ = at::empty({C, height, width, D}, f32(means2d));
+    Tensor ra = at::empty({C, height, width, 1}, f32(means2d));
+    OptT last;
+    if (want_last) last = at::empty({C, height, width}, i32(means2d));
+    const int rc = sc_rasterize_fwd(fp(means2d), fp(conics), fp(colors), fp(opacities), fpo(backgrounds),
+                                    masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr, (int)C, (int)N, (int)D,
+                                    (int)width, (int)height, (int)tile_size, (int)tw, (int)th, ip(offsets), ip(flatten_ids),
+                                    flatten_ids.numel(), fpw(rc_), fpw(ra),
+                                    last ? static_cast<int32_t*>(last->data_ptr()) : nullptr,
+                                    order ? ip(*order) : nullptr, work ? static_cast<int32_t*>(work->data_ptr()) : nullptr,
+                                    S(stream));
+    return py::make_tuple(rc, rc_, ra, last);
+}
+
+// ONE zero-filled buffer for the five gradient outputs (the kernel accumulates with float atomics).
+// -> (rc, v_means2d, v_conics, v_colors, v_opacities, v_means2d_abs | None)
+py::tuple rasterize_bwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                        const Tensor& offsets, const Tensor& flatten_ids, const Tensor& render_alphas, const Tensor& last_ids,
+                        const Tensor& v_render_colors, const Tensor& v_render_alphas, bool absgrad, const OptT& order,
+                        int64_t stream) {
+    req(v_render_colors, at::kFloat, "v_render_colors"); req(v_render_alphas, at::kFloat, "v_render_alphas");
+    req(last_ids, at::kInt, "last_ids");
+    const int64_t C = opacities.size(0), N = opacities.size(1), D = colors.size(-1), CN = C * N;
+    const int64_t th = offsets.size(1), tw = offsets.size(2);
+    const int64_t sizes[5] = {2 * CN, 3 * CN, D * CN, CN, absgrad ? 2 * CN : 0};
+    Tensor flat = at::zeros({sizes[0] + sizes[1] + sizes[2] + sizes[3] + sizes[4]}, f32(means2d));
+    int64_t o = 0;
+    Tensor v_m = flat.narrow(0, o, sizes[0]).view({C, N, 2}); o += sizes[0];
+    Tensor v_c = flat.narrow(0, o, sizes[1]).view({C, N, 3}); o += sizes[1];
+    Tensor v_col = flat.narrow(0, o, sizes[2]).view({C, N, D}); o += sizes[2];
+    Tensor v_o = flat.narrow(0, o, sizes[3]).view({C, N}); o += sizes[3];
+    OptT v_abs;
+    if (absgrad) v_abs = flat.narrow(0, o, sizes[4]).view({C, N, 2});
+    const int rc = sc_rasterize_bwd(fp(means2d), fp(conics), fp(colors), fp(opacities), fpo(backgrounds),
+                                    masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr, (int)C, (int)N, (int)D,
+                                    (int)width, (int)height, (int)tile_size, (int)tw, (int)th, ip(offsets), ip(flatten_ids),
+                                    flatten_ids.numel(), fp(render_alphas), ip(last_ids), fp(v_render_colors),
+                                    fp(v_render_alphas), v_abs ? fpw(*v_abs) : nullptr, fpw(v_m), fpw(v_c), fpw(v_col),
+                                    fpw(v_o), order ? ip(*order) : nullptr, S(stream));
+    return py::make_tuple(rc, v_m, v_c, v_col, v_o, v_abs);
+}
+
+// ---- frame export ---------------------------------------------------------------------------------------------
+int frame_composite_u8(int64_t fg_ptr, int64_t fg_stride, int64_t acc_ptr, int64_t sky_ptr, int64_t sky_stride,
+                       int64_t n_pixels, int64_t rounding, const Tensor& out, int64_t stream) {
+    return sc_frame_composite_u8(reinterpret_cast<const float*>(static_cast<uintptr_t>(fg_ptr)), (int)fg_stride,
+                                 reinterpret_cast<const float*>(static_cast<uintptr_t>(acc_ptr)),
+                                 reinterpret_cast<const float*>(static_cast<uintptr_t>(sky_ptr)), (int)sky_stride, n_pixels,
+                                 (int)rounding, static_cast<uint8_t*>(out.data_ptr()), S(stream));
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "street_crafter_amd: compiled Python <-> C-ABI binding layer (allocation + call per operator)";
+    m.def("abi_version", []() { return std::string(sc_version()); });
+    m.def("projection_fwd", &projection_fwd);
+    m.def("projection_bwd", &projection_bwd);
+    m.def("isect_bin_count", &isect_bin_count);
+    m.def("isect_bin_sort", &isect_bin_sort);
+    m.def("wait_i64", &wait_i64);
+    m.def("sh_fwd", &sh_fwd);
+    m.def("sh_bwd", &sh_bwd);
+    m.def("rasterize_fwd", &rasterize_fwd);
+    m.def("rasterize_bwd", &rasterize_bwd);
+    m.def("frame_composite_u8", &frame_composite_u8);
+}

@@ -79,11 +79,18 @@ def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
         if fg is not None and (sky_rgb_chw is None or (sky is not None and a.is_contiguous()
                                                       and a.dtype == torch.float32)):
             from . import _lib
-            _lib.check(_lib.load().sc_frame_composite_u8(
-                fg[0].data_ptr(), fg[1], None if a is None else a.data_ptr(),
-                None if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1], H * W,
-                ROUNDING[rounding], out.data_ptr(), _raw_stream(x)),
-                "sc_frame_composite_u8")
+            fast = _lib.fast()
+            if fast is not None:
+                rc = fast.frame_composite_u8(fg[0].data_ptr(), fg[1], 0 if a is None else a.data_ptr(),
+                                             0 if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1],
+                                             H * W, ROUNDING[rounding], out, _raw_stream(x))
+            else:
+                rc = _lib.load().sc_frame_composite_u8(
+                    fg[0].data_ptr(), fg[1], None if a is None else a.data_ptr(),
+                    None if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1], H * W,
+                    ROUNDING[rounding], out.data_ptr(), _raw_stream(x))
+            if rc:
+                _lib.check(rc, "sc_frame_composite_u8")
             return out
     v = x.float().clamp(0.0, 1.0)
     if sky_rgb_chw is not None:

@@ -81,6 +81,7 @@ class _NoGradCtx:
 
 
 _NO_GRAD_CTX = _NoGradCtx()
+_EMPTY = {}            # device -> a zero-element tensor (placeholder for None in save_for_backward)
 
 
 def _call(fn, *args):
@@ -94,6 +95,37 @@ def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# Measurement hook (bench.py's train-step roofline): autograd calls the backward operators itself, so a harness
+# cannot bracket them.  With a dict set here, every backward operator appends a (start, end) pair of HIP events,
+# recorded on the current stream around its kernel launch, under its own name.  None (the default): nothing.
+_BACKWARD_PROBE = {"events": None}
+
+
+def set_backward_probe(events):
+    """events: dict name -> list to append (torch.cuda.Event, torch.cuda.Event) pairs to, or None.  Returns the old one."""
+    prev, _BACKWARD_PROBE["events"] = _BACKWARD_PROBE["events"], events
+    return prev
+
+
+class _probe:
+    __slots__ = ("name", "ev")
+
+    def __init__(self, name):
+        self.name, self.ev = name, None
+
+    def __enter__(self):
+        if _BACKWARD_PROBE["events"] is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            self.ev[1].record()
+            _BACKWARD_PROBE["events"].setdefault(self.name, []).append(self.ev)
+        return False
+
+
 # ------------------------------------------------------------------------------------------
 # a1 fully_fused_projection  (renderer.py:219-232)
 # ------------------------------------------------------------------------------------------
@@ -104,16 +136,24 @@ class _Projection(torch.autograd.Function):
         lib = _lib.load()
         C, N = viewmats.shape[0], means.shape[0]
         dev = means.device
-        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
-        means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
-        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
-        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
-        comps = torch.empty((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
-        _lib.check(lib.sc_projection_fwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N,
-                                         int(width), int(height), float(eps2d), float(near_plane),
-                                         float(far_plane), float(radius_clip), _p(radii), _p(means2d),
-                                         _p(depths), _p(conics), _p(comps), _stream(means)),
-                   "sc_projection_fwd")
+        fast = _lib.fast()
+        if fast is not None:
+            rc, radii, means2d, depths, conics, comps = fast.projection_fwd(
+                means, quats, scales, viewmats, Ks, int(width), int(height), float(eps2d), float(near_plane),
+                float(far_plane), float(radius_clip), bool(calc_compensations), _stream(means))
+            if rc:
+                _lib.check(rc, "sc_projection_fwd")
+        else:
+            radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+            means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+            depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+            conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+            comps = torch.empty((C, N), dtype=torch.float32, device=dev) if calc_compensations else None
+            _lib.check(lib.sc_projection_fwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N,
+                                             int(width), int(height), float(eps2d), float(near_plane),
+                                             float(far_plane), float(radius_clip), _p(radii), _p(means2d),
+                                             _p(depths), _p(conics), _p(comps), _stream(means)),
+                       "sc_projection_fwd")
         ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii, conics,
                               comps if comps is not None else torch.empty(0, device=dev))
         ctx.dims = (int(width), int(height), float(eps2d), bool(calc_compensations))
@@ -138,15 +178,28 @@ class _Projection(torch.autograd.Function):
         v_conics = z(v_conics, (C, N, 3))
         if has_comp:
             v_comps = z(v_comps, (C, N))
+        fast = _lib.fast()
+        if fast is not None:
+            with _probe("projection_bwd"):
+                rc, v_means, v_quats, v_scales = fast.projection_bwd(
+                    means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics, comps if has_comp else None,
+                    v_means2d, v_depths, v_conics, v_comps if has_comp else None, _stream(means))
+            if rc:
+                _lib.check(rc, "sc_projection_bwd")
+            return (v_means if ctx.needs_input_grad[0] else None,
+                    v_quats if ctx.needs_input_grad[1] else None,
+                    v_scales if ctx.needs_input_grad[2] else None,
+                    None, None, None, None, None, None, None, None, None)
         v_means = torch.empty_like(means)
         v_quats = torch.empty_like(quats)
         v_scales = torch.empty_like(scales)
-        _lib.check(lib.sc_projection_bwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N, width,
-                                         height, eps2d, _p(radii), _p(conics),
-                                         _p(comps) if has_comp else None, _p(v_means2d), _p(v_depths),
-                                         _p(v_conics), _p(v_comps) if has_comp else None, _p(v_means),
-                                         _p(v_quats), _p(v_scales), _stream(means)),
-                   "sc_projection_bwd")
+        with _probe("projection_bwd"):
+            _lib.check(lib.sc_projection_bwd(_p(means), _p(quats), _p(scales), _p(viewmats), _p(Ks), C, N, width,
+                                             height, eps2d, _p(radii), _p(conics),
+                                             _p(comps) if has_comp else None, _p(v_means2d), _p(v_depths),
+                                             _p(v_conics), _p(v_comps) if has_comp else None, _p(v_means),
+                                             _p(v_quats), _p(v_scales), _stream(means)),
+                       "sc_projection_bwd")
         return (v_means if ctx.needs_input_grad[0] else None,
                 v_quats if ctx.needs_input_grad[1] else None,
                 v_scales if ctx.needs_input_grad[2] else None,
@@ -211,14 +264,14 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         assert int(n_cameras) == C, (n_cameras, C)
     dev = means2d.device
     st = _stream(means2d)
-    tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
-    total_dev = torch.empty(1, dtype=torch.int64, device=dev)
     mode = _ISECT_MODE["mode"] if sort else "radix"
     if mode == "bin":
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, total_dev, st, viewmats=view_cams)
+                               None, None, st, viewmats=view_cams)
         if res is not None:
             return res[:3]
+    tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
+    total_dev = torch.empty(1, dtype=torch.int64, device=dev)
     wsb = lib.sc_isect_workspace_bytes(C * N)
     ws = _ws(wsb, dev)
     _lib.check(lib.sc_isect_count(_p(means2d), _p(radii), C, N, int(tile_size), int(tile_width),
@@ -260,6 +313,7 @@ def _check_isect_count(n_isects, C, N, tile_width, tile_height):
 _BIN_PREDICTION = {}
 _BIN_HISTORY = {}      # same key -> the sizes of the last 8 calls (the prediction covers the largest of them)
 _BIN_HISTORY_LEN = 8   # (tools/exp_camera_rig.py sets 1 for its A/B: round 2's first form)
+_BIN_KEYS_MAX = 64     # shapes remembered in _BIN_HISTORY / _BIN_PREDICTION / _BIN_LAST_META (pruned together)
 _TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [view slots, C * tiles]: the list entries every tile
                        # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
 _TILE_ORDER = {"on": True}
@@ -345,11 +399,11 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
     its sizes through a pinned slot + sequence number per (host thread, device), and the wait for it releases
     the GIL (sc_wait_i64) -- a host that renders two frames in flight from two threads keeps launching one frame
-    while it waits for the other's counts (dist.render_sharded(host_threads=True))."""
+    while it waits for the other's counts (dist.render_sharded(host_threads=True)).
+    `tiles_per_gauss`: None = allocated here (the compiled binding layer allocates every output of the count phase
+    in its one call)."""
     dev = means2d.device
-    offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
-    meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
-    ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
+    fast = _lib.fast()
     # meta (output sizes) comes back through host-mapped pinned memory that the device writes
     # directly, followed by a sequence number: no D2H copy and no event on the stream (include/*.h)
     slots = getattr(_PINNED_META, "slots", None)
@@ -358,43 +412,63 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     slot = slots.get(dev.index)
     if slot is None:
         host = torch.zeros(8, dtype=torch.int64, pin_memory=True)
-        slot = slots[dev.index] = [host, host.numpy(), 0]
-    meta_host, meta_np = slot[0], slot[1]
+        slot = slots[dev.index] = [host, host.numpy(), 0, host.data_ptr()]
+    meta_np, meta_ptr = slot[1], slot[3]
     slot[2] += 1
     seq = slot[2]
     # the rasterizer's dispatch order (longest-running tiles first) is built here, beside the count kernels, from
     # what every tile walked the last time (tile_size 16: the wave-per-tile rasterizer)
-    sched = None
-    if _TILE_ORDER["on"] and int(tile_size) == 16:
-        sched = (torch.empty(lib.sc_tile_order_len(C * tile_width * tile_height), dtype=torch.int32, device=dev),
-                 _tile_work(dev, C, N, tile_width, tile_height))
+    want_order = _TILE_ORDER["on"] and int(tile_size) == 16
+    work = _tile_work(dev, C, N, tile_width, tile_height) if want_order else None
     registry = None
-    if (sched is not None and viewmats is not None and viewmats.device == dev and viewmats.dtype == torch.float32
+    if (want_order and viewmats is not None and viewmats.device == dev and viewmats.dtype == torch.float32
             and viewmats.is_contiguous() and viewmats.shape == (C, 4, 4)):
         registry = _view_registry(dev)
     if registry is None:
         viewmats = None
-    rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
-                                int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
-                                meta_host.data_ptr(), seq, _p(ws0), ws0.numel(),
-                                None if sched is None else _p(sched[1]), _p(viewmats), _p(registry),
-                                None if sched is None else _p(sched[0]), st)
-    if sched is not None:
-        offsets._sc_sched = sched          # travels with isect_offsets to rasterize_to_pixels
+    if fast is not None:
+        rc, tpg, offsets, meta_dev, ws0, order = fast.isect_bin_count(
+            means2d, radii, depths, int(tile_size), int(tile_width), int(tile_height), work, viewmats, registry,
+            bool(want_order), meta_ptr, seq, st)
+        if tiles_per_gauss is not None and rc == 0:
+            tiles_per_gauss.copy_(tpg)            # (a caller that brought its own buffer; none in this package)
+        else:
+            tiles_per_gauss = tpg
+    else:
+        if tiles_per_gauss is None:
+            tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
+        offsets = torch.empty((C, tile_height, tile_width), dtype=torch.int32, device=dev)
+        meta_dev = torch.empty(4, dtype=torch.int64, device=dev)
+        ws0 = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, -1), dev)
+        order = (torch.empty(lib.sc_tile_order_len(C * tile_width * tile_height), dtype=torch.int32, device=dev)
+                 if want_order else None)
+        rc = lib.sc_isect_bin_count(_p(means2d), _p(radii), _p(depths), C, N, int(tile_size), int(tile_width),
+                                    int(tile_height), _p(tiles_per_gauss), _p(offsets), _p(meta_dev),
+                                    meta_ptr, seq, _p(ws0), ws0.numel(),
+                                    _p(work) if want_order else None, _p(viewmats), _p(registry), _p(order), st)
+    if want_order:
+        offsets._sc_sched = (order, work)          # travels with isect_offsets to rasterize_to_pixels
     if rc == -3:     # SC_EUNSUPPORTED -> reference-shaped route
         return None
-    _lib.check(rc, "sc_isect_bin_count")
+    if rc:
+        _lib.check(rc, "sc_isect_bin_count")
 
     def read_meta():
         # wait for the sequence number (a spin in C that holds no GIL); if the GPU is far behind (or something went
         # wrong) fall back to a plain synchronising copy after 2 s
-        if lib.sc_wait_i64(meta_host.data_ptr() + 32, seq, 2_000_000) != 0:
+        waited = (fast.wait_i64(meta_ptr + 32, seq, 2_000_000) if fast is not None
+                  else lib.sc_wait_i64(meta_ptr + 32, seq, 2_000_000))
+        if waited != 0:
             return tuple(int(v) for v in meta_dev.cpu().tolist())
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
     eager_ids = want_ids and not _LAZY_ISECT_IDS["on"]
 
     def launch(capacity, rec_capacity, super_capacity):
+        if fast is not None:
+            return fast.isect_bin_sort(means2d, radii, depths, int(tile_size), int(tile_width), int(tile_height), offsets,
+                                       meta_dev, ws0, int(capacity), int(rec_capacity), int(super_capacity),
+                                       bool(eager_ids), st)
         ids = torch.empty(capacity, dtype=torch.int64, device=dev) if eager_ids else None
         fids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws = _ws(lib.sc_isect_bin_workspace_bytes(C * N, C, tile_width, tile_height, rec_capacity), dev)
@@ -437,8 +511,13 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     hist = _BIN_HISTORY.get(key)
     if hist is None:
         hist = _BIN_HISTORY[key] = collections.deque(maxlen=_BIN_HISTORY_LEN)
-        while len(_BIN_HISTORY) > 64:
-            _BIN_HISTORY.pop(next(iter(_BIN_HISTORY)))
+        while len(_BIN_HISTORY) > _BIN_KEYS_MAX:
+            # one key per distinct (device, C, N, tile grid): densification changes N every 100 training iterations
+            # (train.py:292-310), so all three per-shape tables are pruned together, oldest shape first
+            old = next(iter(_BIN_HISTORY))
+            _BIN_HISTORY.pop(old)
+            _BIN_PREDICTION.pop(old, None)
+            _BIN_LAST_META.pop(old, None)
     hist.append((n_isects, n_records, max_super))
     mi, mr, ms = (max(h[j] for h in hist) for j in range(3))
     _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
@@ -449,15 +528,15 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             isect_ids = ids[:n_isects]
         else:
             # allocated now, written on first use (one kernel, from flatten_ids / offsets / depths)
-            producer = torch.cuda.current_stream(dev)
-
-            def fill(buf, fl=flatten_ids, off=offsets, dep=depths, producer=producer):
-                cur = torch.cuda.current_stream(dev)
-                if cur != producer:
-                    cur.wait_stream(producer)
+            def fill(buf, fl=flatten_ids, off=offsets, dep=depths, producer=st):
+                cur = _stream(buf)
+                if cur != producer:            # filled from another stream than the one that sorted: order them
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.ExternalStream(producer, device=dev))
+                    torch.cuda.current_stream(dev).wait_event(ev)
                 _lib.check(lib.sc_isect_ids_rebuild(fl.data_ptr(), off.data_ptr(), dep.data_ptr(), C, N,
                                                     int(tile_width), int(tile_height), n_isects, buf.data_ptr(),
-                                                    cur.cuda_stream), "sc_isect_ids_rebuild")
+                                                    cur), "sc_isect_ids_rebuild")
 
             from .lazy import LazyTensor
             isect_ids = LazyTensor(torch.empty(n_isects, dtype=torch.int64, device=dev), fill)
@@ -494,9 +573,15 @@ class _SphericalHarmonics(torch.autograd.Function):
         lib = _lib.load()
         M = dirs.numel() // 3
         K = coeffs.shape[-2]
-        colors = torch.empty(dirs.shape, dtype=torch.float32, device=dirs.device)
-        _lib.check(lib.sc_sh_fwd(int(degree), _p(dirs), _p(coeffs), _p(masks), M, K, _p(colors),
-                                 _stream(dirs)), "sc_sh_fwd")
+        fast = _lib.fast()
+        if fast is not None:
+            rc, colors = fast.sh_fwd(int(degree), dirs, coeffs, masks, _stream(dirs))
+            if rc:
+                _lib.check(rc, "sc_sh_fwd")
+        else:
+            colors = torch.empty(dirs.shape, dtype=torch.float32, device=dirs.device)
+            _lib.check(lib.sc_sh_fwd(int(degree), _p(dirs), _p(coeffs), _p(masks), M, K, _p(colors),
+                                     _stream(dirs)), "sc_sh_fwd")
         ctx.save_for_backward(dirs, coeffs, masks if masks is not None else torch.empty(0, device=dirs.device))
         ctx.meta = (int(degree), M, K, masks is not None)
         return colors
@@ -507,11 +592,20 @@ class _SphericalHarmonics(torch.autograd.Function):
         dirs, coeffs, masks = ctx.saved_tensors
         degree, M, K, has_mask = ctx.meta
         v_colors = v_colors.contiguous()
-        v_coeffs = torch.empty_like(coeffs)
         need_dirs = ctx.needs_input_grad[1]
+        fast = _lib.fast()
+        if fast is not None:
+            with _probe("spherical_harmonics_bwd"):
+                rc, v_coeffs, v_dirs = fast.sh_bwd(degree, dirs, coeffs, masks if has_mask else None, v_colors,
+                                                   bool(need_dirs), _stream(dirs))
+            if rc:
+                _lib.check(rc, "sc_sh_bwd")
+            return None, v_dirs, (v_coeffs if ctx.needs_input_grad[2] else None), None
+        v_coeffs = torch.empty_like(coeffs)
         v_dirs = torch.empty_like(dirs) if need_dirs else None
-        _lib.check(lib.sc_sh_bwd(degree, _p(dirs), _p(coeffs), _p(masks) if has_mask else None, M, K,
-                                 _p(v_colors), _p(v_coeffs), _p(v_dirs), _stream(dirs)), "sc_sh_bwd")
+        with _probe("spherical_harmonics_bwd"):
+            _lib.check(lib.sc_sh_bwd(degree, _p(dirs), _p(coeffs), _p(masks) if has_mask else None, M, K,
+                                     _p(v_colors), _p(v_coeffs), _p(v_dirs), _stream(dirs)), "sc_sh_bwd")
         return None, v_dirs, (v_coeffs if ctx.needs_input_grad[2] else None), None
 
 
@@ -558,19 +652,29 @@ class _Rasterize(torch.autograd.Function):
         D = colors.shape[-1]
         th, tw = isect_offsets.shape[1], isect_offsets.shape[2]
         dev = means2d.device
-        render_colors = torch.empty((C, height, width, D), dtype=torch.float32, device=dev)
-        render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
         # last_ids only feeds the backward replay: inference (no input requires grad) skips it
         needs_bwd = any(ctx.needs_input_grad[:5])
-        last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev) if needs_bwd else None
         order, work = _sched_of(isect_offsets, C * tw * th)
-        _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
-                                        _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
-                                        _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-                                        _p(render_colors), _p(render_alphas), _p(last_ids), _p(order), _p(work),
-                                        _stream(means2d)),
-                   "sc_rasterize_fwd")
-        e = torch.empty(0, device=dev)
+        fast = _lib.fast()
+        if fast is not None:
+            rc, render_colors, render_alphas, last_ids = fast.rasterize_fwd(
+                means2d, conics, colors, opacities, backgrounds, masks, int(width), int(height), int(tile_size),
+                isect_offsets, flatten_ids, bool(needs_bwd), order, work, _stream(means2d))
+            if rc:
+                _lib.check(rc, "sc_rasterize_fwd")
+        else:
+            render_colors = torch.empty((C, height, width, D), dtype=torch.float32, device=dev)
+            render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
+            last_ids = torch.empty((C, height, width), dtype=torch.int32, device=dev) if needs_bwd else None
+            _lib.check(lib.sc_rasterize_fwd(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
+                                            _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
+                                            _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+                                            _p(render_colors), _p(render_alphas), _p(last_ids), _p(order), _p(work),
+                                            _stream(means2d)),
+                       "sc_rasterize_fwd")
+        e = _EMPTY.get(dev)
+        if e is None:
+            e = _EMPTY[dev] = torch.empty(0, device=dev)
         ctx.save_for_backward(means2d, conics, colors, opacities, backgrounds if backgrounds is not None else e,
                               masks if masks is not None else e, isect_offsets, flatten_ids, render_alphas,
                               last_ids if last_ids is not None else e)
@@ -592,6 +696,21 @@ class _Rasterize(torch.autograd.Function):
         dev = means2d.device
         v_render_colors = v_render_colors.contiguous()
         v_render_alphas = v_render_alphas.contiguous()
+        fast = _lib.fast()
+        if fast is not None:
+            with _probe("rasterize_to_pixels_bwd"):
+                rc, v_means2d, v_conics, v_colors, v_opacities, v_abs = fast.rasterize_bwd(
+                    means2d, conics, colors, opacities, backgrounds if has_bg else None, masks if has_mask else None,
+                    width, height, tile_size, isect_offsets, flatten_ids, render_alphas, last_ids, v_render_colors,
+                    v_render_alphas, bool(absgrad), ctx.tile_order, _stream(means2d))
+            if rc:
+                _lib.check(rc, "sc_rasterize_bwd")
+            if absgrad:
+                ctx.means2d_obj.tensor.absgrad = v_abs          # gsplat contract (street_gaussian_model.py:505-506)
+            v_bg = None
+            if has_bg and ctx.needs_input_grad[4]:
+                v_bg = (v_render_colors * (1.0 - render_alphas)).sum(dim=(1, 2))
+            return (v_means2d, v_conics, v_colors, v_opacities, v_bg, None, None, None, None, None, None, None, None)
         # the kernel accumulates with float atomics: ONE zero-fill for all five gradient buffers
         sizes = (2 * C * N, 3 * C * N, D * C * N, C * N, 2 * C * N if absgrad else 0)
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -601,14 +720,15 @@ class _Rasterize(torch.autograd.Function):
         v_colors = parts[2].view(C, N, D)
         v_opacities = parts[3].view(C, N)
         v_abs = parts[4].view(C, N, 2) if absgrad else None
-        _lib.check(lib.sc_rasterize_bwd(_p(means2d), _p(conics), _p(colors), _p(opacities),
-                                        _p(backgrounds) if has_bg else None, _p(masks) if has_mask else None,
-                                        C, N, D, width, height, tile_size, tw, th, _p(isect_offsets),
-                                        _p(flatten_ids), flatten_ids.numel(), _p(render_alphas), _p(last_ids),
-                                        _p(v_render_colors), _p(v_render_alphas), _p(v_abs), _p(v_means2d),
-                                        _p(v_conics), _p(v_colors), _p(v_opacities), _p(ctx.tile_order),
-                                        _stream(means2d)),
-                   "sc_rasterize_bwd")
+        with _probe("rasterize_to_pixels_bwd"):
+            _lib.check(lib.sc_rasterize_bwd(_p(means2d), _p(conics), _p(colors), _p(opacities),
+                                            _p(backgrounds) if has_bg else None, _p(masks) if has_mask else None,
+                                            C, N, D, width, height, tile_size, tw, th, _p(isect_offsets),
+                                            _p(flatten_ids), flatten_ids.numel(), _p(render_alphas), _p(last_ids),
+                                            _p(v_render_colors), _p(v_render_alphas), _p(v_abs), _p(v_means2d),
+                                            _p(v_conics), _p(v_colors), _p(v_opacities), _p(ctx.tile_order),
+                                            _stream(means2d)),
+                       "sc_rasterize_bwd")
         if absgrad:
             # gsplat contract: the tensor object the CALLER passed gets an `.absgrad` attribute
             # (read at street_gaussian/models/street_gaussian_model.py:505-506)
@@ -786,9 +906,8 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     tile_height = math.ceil(height / float(tile_size))
     res = None
     if _ISECT_MODE["mode"] == "bin":
-        tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               tiles_per_gauss, None, st, want_ids=False, viewmats=viewmats)
+                               None, None, st, want_ids=False, viewmats=viewmats)
     if res is not None:
         tiles_per_gauss, isect_ids, flatten_ids, isect_offsets = res
     else:

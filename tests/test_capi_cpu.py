@@ -264,6 +264,29 @@ def test_bench_algorithmic_bytes_are_the_survey_formula():
         assert algorithmic_bytes(N, I, W, H, 16, K) == total
 
 
+def test_bench_refuses_stale_pmc_traffic_records():
+    """bench.py's `roofline.traffic` comes from committed rocprofv3 --pmc passes; a record collected on another kernel
+    symbol (or one that does not say which) must not be reported."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sym = bench.OPERATOR_KERNEL["rasterize_to_pixels"]
+    good = {"rasterize_to_pixels": {"n1000000": 2.0e8}, "_kernels": {"n1000000": {"rasterize_to_pixels": [sym]}}}
+    assert bench.pmc_traffic_entry(good, "rasterize_to_pixels", "n1000000", sym)[0] == 2.0e8
+    assert bench.pmc_traffic_entry(good, "rasterize_to_pixels", "n1000000", "raster_fwd_wave_kernel<4, false, false>")[0] is None
+    assert bench.pmc_traffic_entry(good, "rasterize_to_pixels", "n5", sym)[0] is None
+    assert bench.pmc_traffic_entry({"rasterize_to_pixels": {"n1000000": 2.0e8}}, "rasterize_to_pixels", "n1000000", sym)[0] is None
+    # the backward's byte model: 92 B per intersection + 28 B per pixel (DESIGN.md section 4); knn: 104 B per point
+    assert bench.raster_bwd_algorithmic_bytes(1000, 10) == 92 * 1000 + 280 and bench.KNN_BYTES_PER_POINT == 104
+    # the committed record, if present, must be usable by THIS build's kernel symbols or be refused -- never misread
+    tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tj):
+        import json
+        val, why = bench.pmc_traffic_entry(json.load(open(tj)), "rasterize_to_pixels", "n1000000", sym)
+        assert val is None or val > 1e6, (val, why)
+
+
 def test_lazy_tensor_fills_on_first_read_only():
     """street_crafter_amd/lazy.py: metadata never triggers the fill, any read does, exactly once."""
     import numpy as np

@@ -1349,6 +1349,66 @@ def test_speculative_sort_is_sized_for_the_fullest_of_the_recent_views(ops):
         np.testing.assert_array_equal(frames[f].view(np.uint32), frames[f - 2].view(np.uint32))
 
 
+def test_compiled_binding_layer_equals_the_ctypes_table(ops):
+    """street_crafter_amd/csrc/binding.cpp (the default host path: one compiled call per operator allocates the outputs
+    and calls the C ABI) against the ctypes table of _lib.py (the same C ABI called from Python): every forward tensor
+    of a train-mode frame bit-identical, gradients equal up to the backward's atomic summation order; the binding is
+    what the rest of this suite runs through (`_lib.fast()` is not None)."""
+    from street_crafter_amd import _lib
+    from harness.caller import render_gaussians
+    assert _lib.fast() is not None and _lib.fast().abi_version().encode() == _lib.load().sc_version()
+    cam = make_camera(320, 208, 300.0, 300.0).to(DEV)
+    base = make_scene(20_000, seed=9, z_range=(1.0, 30.0), scale_range=(0.01, 0.25))
+    outs = {}
+    for fast_on in (True, False):
+        prev = _lib.set_fast_binding(fast_on)
+        try:
+            assert (_lib.fast() is not None) == fast_on
+            sc = base.to(DEV)
+            ps = (sc.means, sc.quats, sc.scales, sc.opacities, sc.sh)
+            for t in ps:
+                t.requires_grad_(True)
+            for _ in range(2):                      # second frame: warm dispatch list, speculative sort
+                for t in ps:
+                    t.grad = None
+                o = render_gaussians(sc, cam, mode="train", return_intermediates=True)
+                (o["rgb"].mean() + o["acc"].mean() + 0.01 * o["depth"].mean()).backward()
+            with torch.no_grad():
+                inf = render_gaussians(sc, cam, return_intermediates=True)
+            torch.cuda.synchronize()
+            outs[fast_on] = (o, inf, [t.grad.clone() for t in ps], o["viewspace_points"].absgrad.clone())
+        finally:
+            _lib.set_fast_binding(prev)
+    keys = ("_radii", "_means2d", "_depths", "_conics", "_compensations", "_opacities", "_tiles_per_gauss", "_isect_ids",
+            "_flatten_ids", "_isect_offsets", "_colors", "_render_colors", "_render_alphas", "rgb", "acc", "depth")
+    for which in (0, 1):
+        for k in keys:
+            assert torch.equal(outs[True][which][k], outs[False][which][k]), (which, k)
+    for ga, gb in zip(outs[True][2], outs[False][2]):
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-7 + 1e-5 * float(gb.abs().max()))
+    assert torch.allclose(outs[True][3], outs[False][3], rtol=1e-4, atol=1e-5 * float(outs[False][3].abs().max()))
+
+
+def test_per_shape_tables_are_pruned_together(ops):
+    """isect_tiles keeps three per-shape tables (sizes history, prediction, last meta), keyed by (device, C, N, tile
+    grid).  Densification changes N every 100 training iterations (train.py:292-310): all three are bounded and pruned
+    together, oldest shape first."""
+    from street_crafter_amd import rendering
+    cam = make_camera(128, 96, 120.0, 120.0).to(DEV)
+    sc = make_scene(400, seed=3, z_range=(1.0, 10.0)).to(DEV)
+    w2c, K = cam.viewmat[None], cam.K[None]
+    with torch.no_grad():
+        for n in range(300, 300 + rendering._BIN_KEYS_MAX + 12):
+            r, m2, d, _, _ = ops.fully_fused_projection(sc.means[:n], None, sc.quats[:n], sc.scales[:n], w2c, K, 128, 96)
+            ops.isect_tiles(m2, r, d, 16, 8, 6, n_cameras=1)
+    torch.cuda.synchronize()
+    keys = set(rendering._BIN_HISTORY)
+    assert len(keys) == rendering._BIN_KEYS_MAX
+    assert set(rendering._BIN_PREDICTION) <= keys and set(rendering._BIN_LAST_META) <= keys
+    newest = (torch.device(DEV).index or 0, 1, 300 + rendering._BIN_KEYS_MAX + 11, 16, 8, 6)
+    assert any(k[2] == newest[2] for k in keys) and not any(k[2] == 300 and k[4:] == (8, 6) for k in keys)
+
+
 def test_frame_without_gaussians_is_rendered_everywhere(ops):
     """N = 0: the intersection stage's short path still hands the rasterizer a dispatch list that names every tile
     (in the list's item format), so the whole frame is written: background colour, alpha 0 -- with the list on, and

@@ -4,7 +4,7 @@
 # flight, the default) and of the same frames one at a time, of the street scenes and of the train step, and
 # the PMC passes.  Copy the *.md / *.json you want judged into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 python3 bench.py --steps 50 --warmup 5 > $O/${TAG}_bench_1gpu_S1M.jsonl 2> $O/${TAG}_bench.err; echo "bench rc=$?"
@@ -22,6 +22,7 @@ prof street3m 12 python3 tools/prof_scene.py street3m 12
 prof sky 20 python3 tools/prof_scene.py sky 20
 prof train_1gpu_S1M 13 python3 tools/exp_train.py 1000000 1600 1066 10
 bash tools/pmc_run.sh $O/pmc_${TAG} > $O/${TAG}_pmc.log 2>&1; echo "pmc rc=$?"
-cp $O/pmc_${TAG}/summary.md $O/${TAG}_pmc_counters_S1M.md
+cp $O/pmc_${TAG}/fwd/summary.md $O/${TAG}_pmc_counters_S1M.md
+cp $O/pmc_${TAG}/train/summary.md $O/${TAG}_pmc_counters_train_S1M.md
 cp $O/pmc_${TAG}/pmc_traffic.json $O/${TAG}_pmc_traffic.json
-rm -rf $O/pmc_${TAG}/pass*
+rm -rf $O/pmc_${TAG}/fwd/pass* $O/pmc_${TAG}/train/pass*
