@@ -17,17 +17,19 @@ _lib = None
 _path = LIB_PATH
 
 
-def use_diagnostic_build():
+def use_diagnostic_build(tag: str = ""):
     """tools/exp_*.py only: load the DIAGNOSTIC build (`python -m street_crafter_amd.build --diag`; same sources
     with the sc_set_option("debug0".."debug3") skip switches compiled in) instead of the shipped library.  Must be
-    called before the first operator call; nothing in the package, tests/ or bench.py calls it."""
+    called before the first operator call; nothing in the package, tests/ or bench.py calls it.
+    `tag`: an experiment build made with SC_DIAG_TAG=tag SC_EXP_DEFS="-D..." (tools/ab_lib.py)."""
     global _path
-    if _lib is not None and _path != DIAG_LIB_PATH:
+    want = DIAG_LIB_PATH.replace("_diag.so", f"_diag_{tag}.so") if tag else DIAG_LIB_PATH
+    if _lib is not None and _path != want:
         raise RuntimeError("use_diagnostic_build() must be called before the library is first loaded")
-    if not os.path.exists(DIAG_LIB_PATH):
-        raise ImportError(f"diagnostic library not built ({DIAG_LIB_PATH} missing): "
+    if not os.path.exists(want):
+        raise ImportError(f"diagnostic library not built ({want} missing): "
                           "python -m street_crafter_amd.build --diag")
-    _path = DIAG_LIB_PATH
+    _path = want
 
 c_f32p = C.c_void_p   # device pointers travel as integers
 c_i32p = C.c_void_p

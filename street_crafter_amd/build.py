@@ -55,10 +55,14 @@ def _stale(target, deps):
 
 
 def _compile(src, force, verbose, diag=False):
-    obj = os.path.join(OBJDIR, "diag" if diag else "", src.replace(".hip", ".o"))
+    tag = os.environ.get("SC_DIAG_TAG", "") if diag else ""
+    obj = os.path.join(OBJDIR, ("diag" + ("_" + tag if tag else "")) if diag else "", src.replace(".hip", ".o"))
     if not force and not _stale(obj, _deps(src)):
         return obj, False
-    cmd = [_hipcc(), *COMMON_FLAGS, *(["-DSC_DIAG"] if diag else []), "-c", os.path.join(CSRC, src), "-o", obj]
+    # (SC_EXP_DEFS: extra -D flags for the DIAGNOSTIC build only -- kernel experiments are A/B-ed as shipped library
+    #  vs diagnostic library, tools/ab_lib.py; the shipped build never sees them)
+    extra = os.environ.get("SC_EXP_DEFS", "").split() if diag else []
+    cmd = [_hipcc(), *COMMON_FLAGS, *(["-DSC_DIAG", *extra] if diag else []), "-c", os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -72,8 +76,9 @@ def _compile(src, force, verbose, diag=False):
 def build(force=False, verbose=False, jobs=None, diag=False):
     """Builds the shipped library (diag=False) or the diagnostic one (diag=True); returns its path."""
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(os.path.join(OBJDIR, "diag") if diag else OBJDIR, exist_ok=True)
-    lib = LIB_DIAG if diag else LIB
+    tag = os.environ.get("SC_DIAG_TAG", "") if diag else ""       # several experiment builds side by side (tools/ab_lib.py)
+    os.makedirs(os.path.join(OBJDIR, "diag" + ("_" + tag if tag else "")) if diag else OBJDIR, exist_ok=True)
+    lib = (LIB_DIAG.replace("_diag.so", f"_diag_{tag}.so") if tag else LIB_DIAG) if diag else LIB
     jobs = jobs or min(len(SOURCES), max(1, (os.cpu_count() or 2) - 1))
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
         results = list(ex.map(lambda s: _compile(s, force, verbose, diag), SOURCES))

@@ -147,31 +147,127 @@ __device__ __forceinline__ float box_dist2(float px, float py, float pz, const M
     return (dx * dx + dy * dy) + dz * dz;
 }
 
+// ---- implicit 32-ary box hierarchy over the curve order ---------------------------------------------------------
+// Level 0: boxes of KNN_FINE = 32 consecutive sorted points; level k + 1: 32 consecutive boxes of level k (1024 points
+// -- simple-knn's box --, 32 768, 1 M, ...).  Round 2 had the 1024-point level only: every point tested all n / 1024
+// boxes and scanned every box that passed in full (~28 k distance evaluations per point at 1 M points: 10.9 ms).
+// With the hierarchy a point descends only into boxes nearer than its current third-nearest distance and scans
+// 32-point leaves (~1 k evaluations).  The RESULT is the exact 3-NN either way -- whatever is visited, the three
+// smallest distances over all other points are what remains, computed with the oracle's op order -- so it stays
+// bit-identical to oracle/knn_oracle.py.
+constexpr int KNN_FINE = 32;
+constexpr int KNN_FAN = 32;
+
+// gather into curve order + the level-0 boxes: lanes l and l ^ 32 of a wave are different boxes
+__global__ __launch_bounds__(256) void knn_gather_leaf_kernel(const float* __restrict__ pts, const int* __restrict__ ids,
+                                                              int64_t n, float* __restrict__ sorted_pts,
+                                                              MinMax* __restrict__ leaves) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (i < n) {
+        const int64_t src = ids[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[src * 3 + a];
+            sorted_pts[i * 3 + a] = v;
+            lo[a] = hi[a] = v;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+        }
+    if ((threadIdx.x & 31) == 0 && i < n) {
+        MinMax m;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { m.lo[a] = lo[a]; m.hi[a] = hi[a]; }
+        leaves[i / KNN_FINE] = m;
+    }
+}
+
+// one 32-lane group per parent box: the union of its (up to) 32 children
+__global__ __launch_bounds__(256) void knn_parent_boxes_kernel(const MinMax* __restrict__ child, int64_t n_child,
+                                                               MinMax* __restrict__ parent, int64_t n_parent) {
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const int64_t c = g * KNN_FAN + l;
+    if (g < n_parent && c < n_child) {
+        const MinMax m = child[c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = m.lo[a]; hi[a] = m.hi[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+        }
+    if (l == 0 && g < n_parent) {
+        MinMax m;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { m.lo[a] = lo[a]; m.hi[a] = hi[a]; }
+        parent[g] = m;
+    }
+}
+
+// exactly KNN_LEVELS levels are built (a level with one box costs one test per wave): fixed nesting, no index stack
+constexpr int KNN_LEVELS = 4;               // leaves of 32 points, then 1024, 32 768 and 1 048 576 points per box
+struct KnnLevels {
+    const MinMax* box[KNN_LEVELS];           // box[0] = leaves
+    int count[KNN_LEVELS];
+};
+
+// One WAVE walks the hierarchy for its 64 consecutive points TOGETHER: a box is entered when ANY lane still needs it
+// (its AABB is no farther than that lane's current bound), and then every lane evaluates it -- extra candidates never
+// change an exact k-NN result, control flow stays wave-uniform, and box / leaf-point addresses are wave-uniform
+// (scalar loads).  Lanes are neighbours on the curve, so the union of their walks is little more than one walk.
 __global__ __launch_bounds__(256) void knn_mean_dist_kernel(const float* __restrict__ sorted_pts,
-                                                            const int* __restrict__ ids, int64_t n,
-                                                            const MinMax* __restrict__ boxes, int nb,
+                                                            const int* __restrict__ ids, int64_t n, KnnLevels lv,
                                                             float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float px = sorted_pts[i * 3 + 0], py = sorted_pts[i * 3 + 1], pz = sorted_pts[i * 3 + 2];
+    const bool live = i < n;
+    const int64_t ic = live ? i : n - 1;
+    const float px = sorted_pts[ic * 3 + 0], py = sorted_pts[ic * 3 + 1], pz = sorted_pts[ic * 3 + 2];
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
-    for (int64_t j = max((int64_t)0, i - 3); j <= min(n - 1, i + 3); ++j) {
-        if (j == i) continue;
-        knn_insert(dist2(px, py, pz, sorted_pts + j * 3), b0, b1, b2);
-    }
-    const float reject = b2;
-    b0 = b1 = b2 = FLT_MAX;
-    for (int b = 0; b < nb; ++b) {
-        const MinMax m = boxes[b];
-        const float bd = box_dist2(px, py, pz, m);
-        if (bd > reject || bd > b2) continue;
-        const int64_t s = (int64_t)b * KNN_BOX, e = min(s + KNN_BOX, n);
-        for (int64_t j = s; j < e; ++j) {
+    if (live)
+        for (int64_t j = max((int64_t)0, i - 3); j <= min(n - 1, i + 3); ++j) {
             if (j == i) continue;
             knn_insert(dist2(px, py, pz, sorted_pts + j * 3), b0, b1, b2);
         }
+    const float reject = b2;
+    b0 = b1 = b2 = FLT_MAX;
+    // a lane "wants" a box iff bd <= min(reject, b2): exactly round 2's test (`bd > reject || bd > b2` skipped)
+    auto wanted = [&](const MinMax* __restrict__ boxes, int b) -> bool {
+        const MinMax m = boxes[__builtin_amdgcn_readfirstlane(b)];
+        const float bd = box_dist2(px, py, pz, m);
+        return __any(live && !(bd > reject || bd > b2));
+    };
+    for (int b3 = 0; b3 < lv.count[3]; ++b3) {
+        if (!wanted(lv.box[3], b3)) continue;
+        const int e2 = min(b3 * KNN_FAN + KNN_FAN, lv.count[2]);
+        for (int b2i = b3 * KNN_FAN; b2i < e2; ++b2i) {
+            if (!wanted(lv.box[2], b2i)) continue;
+            const int e1 = min(b2i * KNN_FAN + KNN_FAN, lv.count[1]);
+            for (int b1i = b2i * KNN_FAN; b1i < e1; ++b1i) {
+                if (!wanted(lv.box[1], b1i)) continue;
+                const int e0 = min(b1i * KNN_FAN + KNN_FAN, lv.count[0]);
+                for (int b0i = b1i * KNN_FAN; b0i < e0; ++b0i) {
+                    if (!wanted(lv.box[0], b0i)) continue;
+                    const int64_t s = (int64_t)__builtin_amdgcn_readfirstlane(b0i) * KNN_FINE, e = min(s + KNN_FINE, n);
+                    for (int64_t j = s; j < e; ++j) {
+                        const float d = dist2(px, py, pz, sorted_pts + j * 3);
+                        if (j != i) knn_insert(d, b0, b1, b2);
+                    }
+                }
+            }
+        }
     }
-    out[ids[i]] = ((b0 + b1) + b2) / 3.0f;
+    if (live) out[ids[i]] = ((b0 + b1) + b2) / 3.0f;
 }
 
 }  // namespace
@@ -183,6 +279,9 @@ extern "C" int sc_radix_sort_pairs_u64_i32(uint64_t*, int32_t*, uint64_t*, int32
 namespace {
 struct KnnLayout {
     size_t keys, tmp_keys, ids, tmp_ids, sorted, boxes, bbox, sort_ws, total;
+    size_t level_off[KNN_LEVELS];
+    int64_t level_count[KNN_LEVELS];
+    int n_levels;
 };
 KnnLayout knn_layout(int64_t n) {
     KnnLayout L;
@@ -193,9 +292,18 @@ KnnLayout knn_layout(int64_t n) {
     L.ids = o; o += sc_align_up((size_t)n * 4, 256);
     L.tmp_ids = o; o += sc_align_up((size_t)n * 4, 256);
     L.sorted = o; o += sc_align_up((size_t)n * 12, 256);
-    L.boxes = o; o += sc_align_up(nb * sizeof(MinMax), 256);
+    L.boxes = o; o += sc_align_up(nb * sizeof(MinMax), 256);       // 1024-point boxes of the UNSORTED input (bbox pass)
     L.bbox = o; o += 256;
     L.sort_ws = o; o += sc_radix_sort_workspace_bytes(n);
+    // the hierarchy: leaves of KNN_FINE points, then fan-in KNN_FAN per level (always KNN_LEVELS levels)
+    int64_t c = (n + KNN_FINE - 1) / KNN_FINE;
+    L.n_levels = KNN_LEVELS;
+    for (int k = 0; k < KNN_LEVELS; ++k) {
+        L.level_count[k] = c;
+        L.level_off[k] = o;
+        o += sc_align_up((size_t)c * sizeof(MinMax), 256);
+        c = (c + KNN_FAN - 1) / KNN_FAN;
+    }
     L.total = o;
     return L;
 }
@@ -236,13 +344,24 @@ extern "C" int sc_knn3_mean_dist2(const float* points, int64_t n, float* out, vo
                                          (int*)(ws + L.tmp_ids), n, 30, ws + L.sort_ws,
                                          sc_radix_sort_workspace_bytes(n), stream);
     if (rc != SC_OK) return rc;
-    // 4. gather into curve order + per-box AABBs
-    hipLaunchKernelGGL(knn_box_minmax_kernel, dim3(nb), dim3(256), 0, s, points, (const int*)ids, n, KNN_BOX,
-                       sorted, boxes);
+    // 4. gather into curve order + the box hierarchy (leaves of 32 points, fan-in 32 per level)
+    hipLaunchKernelGGL(knn_gather_leaf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, points, (const int*)ids,
+                       n, sorted, (MinMax*)(ws + L.level_off[0]));
     SC_LAUNCH_CHECK();
-    // 5. pruned exact scan
+    KnnLevels lv;
+    for (int k = 0; k < KNN_LEVELS; ++k) {
+        lv.box[k] = (const MinMax*)(ws + L.level_off[k]);
+        lv.count[k] = (int)L.level_count[k];
+    }
+    for (int k = 1; k < L.n_levels; ++k) {
+        const int64_t np = L.level_count[k];
+        hipLaunchKernelGGL(knn_parent_boxes_kernel, dim3((unsigned)((np * 32 + 255) / 256)), dim3(256), 0, s, lv.box[k - 1],
+                           L.level_count[k - 1], (MinMax*)(ws + L.level_off[k]), np);
+        SC_LAUNCH_CHECK();
+    }
+    // 5. pruned exact search, one wave per 64 consecutive points of the curve
     hipLaunchKernelGGL(knn_mean_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sorted,
-                       (const int*)ids, n, boxes, nb, out);
+                       (const int*)ids, n, lv, out);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

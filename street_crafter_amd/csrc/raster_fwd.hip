@@ -354,9 +354,16 @@ __device__ __forceinline__ void raster_item(
             // changes nothing -- their x is +inf -- and the vote is 3 VALU + 2 SALU ops and a branch)
             for (;;) {
                 a1 = xyoa_s[t + 1]; b1 = bck_s[t + 1]; c1 = col_s[t + 1];
+                // The scheduler sinks these three LDS reads BELOW the blend of the current record (fewer live
+                // registers), which puts their latency in front of every iteration (ISA of round 2: ds_read x3 then
+                // s_waitcnt lgkmcnt(2) at the loop top).  Pinning them above costs 10 VGPRs (82 -> 92: still 5 waves
+                // per SIMD) and gives -1 us on S-1M, -2..-6 us on the street scene (tools/ab_lib.py,
+                // profiles/r03_raster_prefetch_ab.txt).  Not with TRACK: 98 VGPRs there -> 4 waves per SIMD, +22 us.
+                if constexpr (!TRACK) __builtin_amdgcn_sched_barrier(0);
                 blend(a0, b0, c0);
                 if (++t >= bsz) break;
                 a0 = xyoa_s[t + 1]; b0 = bck_s[t + 1]; c0 = col_s[t + 1];
+                if constexpr (!TRACK) __builtin_amdgcn_sched_barrier(0);
                 blend(a1, b1, c1);
                 if (all_done()) { walked += t + 1 - bsz; break; }
                 if (++t >= bsz) break;
