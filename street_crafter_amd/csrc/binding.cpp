@@ -208,6 +208,53 @@ py::tuple rasterize_bwd(const Tensor& means2d, const Tensor& conics, const Tenso
     return py::make_tuple(rc, v_m, v_c, v_col, v_o, v_abs);
 }
 
+// ---- the fused forward behind gsplat.rendering.rasterization() --------------------------------------
+// -> (rc, radii, means2d, depths, records | None, conics | None, opacities | None, colors4 | None)
+py::tuple projection_sh_fwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& opacities,
+                            const Tensor& sh, const Tensor& viewmats, const Tensor& Ks, const Tensor& centers,
+                            int64_t sh_degree, int64_t width, int64_t height, double eps2d, double near_plane,
+                            double far_plane, double radius_clip, bool antialiased, bool want_records, int64_t stream) {
+    req(means, at::kFloat, "means"); req(quats, at::kFloat, "quats"); req(scales, at::kFloat, "scales");
+    req(opacities, at::kFloat, "opacities"); req(sh, at::kFloat, "colors"); req(viewmats, at::kFloat, "viewmats");
+    req(Ks, at::kFloat, "Ks"); req(centers, at::kFloat, "camera_centers");
+    const int64_t C = viewmats.size(0), N = means.size(0), K = sh.size(1);
+    Tensor radii = at::empty({C, N}, i32(means));
+    Tensor means2d = at::empty({C, N, 2}, f32(means));
+    Tensor depths = at::empty({C, N}, f32(means));
+    OptT records, conics, opac, cols;
+    if (want_records) {
+        records = at::empty({C, N, 12}, f32(means));
+    } else {
+        conics = at::empty({C, N, 3}, f32(means));
+        opac = at::empty({C, N}, f32(means));
+        cols = at::empty({C, N, 4}, f32(means));
+    }
+    const int rc = sc_projection_sh_fwd(fp(means), fp(quats), fp(scales), fp(opacities), fp(sh), fp(viewmats), fp(Ks),
+                                        fp(centers), (int)C, (int)N, (int)K, (int)sh_degree, (int)width, (int)height,
+                                        (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip,
+                                        antialiased ? 1 : 0, static_cast<int32_t*>(radii.data_ptr()), fpw(means2d),
+                                        fpw(depths), conics ? fpw(*conics) : nullptr, opac ? fpw(*opac) : nullptr,
+                                        cols ? fpw(*cols) : nullptr, records ? fpw(*records) : nullptr, S(stream));
+    return py::make_tuple(rc, radii, means2d, depths, records, conics, opac, cols);
+}
+
+// -> (rc, render_colors [C,H,W,4], render_alphas [C,H,W,1])
+py::tuple rasterize_fwd_packed(const Tensor& records, const OptT& backgrounds, int64_t width, int64_t height,
+                               const Tensor& offsets, const Tensor& flatten_ids, const OptT& order, const OptT& work,
+                               bool depth_normalise, int64_t stream) {
+    req(records, at::kFloat, "records"); req(offsets, at::kInt, "isect_offsets"); req(flatten_ids, at::kInt, "flatten_ids");
+    const int64_t C = records.size(0), N = records.size(1);
+    const int64_t th = offsets.size(1), tw = offsets.size(2);
+    Tensor rc_ = at::empty({C, height, width, 4}, f32(records));
+    Tensor ra = at::empty({C, height, width, 1}, f32(records));
+    const int rc = sc_rasterize_fwd_packed(fp(records), fpo(backgrounds), nullptr, (int)C, (int)N, (int)width, (int)height,
+                                           (int)tw, (int)th, ip(offsets), ip(flatten_ids), flatten_ids.numel(), fpw(rc_),
+                                           fpw(ra), order ? ip(*order) : nullptr,
+                                           work ? static_cast<int32_t*>(work->data_ptr()) : nullptr,
+                                           depth_normalise ? 1 : 0, S(stream));
+    return py::make_tuple(rc, rc_, ra);
+}
+
 // ---- frame export ---------------------------------------------------------------------------------------------
 int frame_composite_u8(int64_t fg_ptr, int64_t fg_stride, int64_t acc_ptr, int64_t sky_ptr, int64_t sky_stride,
                        int64_t n_pixels, int64_t rounding, const Tensor& out, int64_t stream) {
@@ -231,5 +278,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("sh_bwd", &sh_bwd);
     m.def("rasterize_fwd", &rasterize_fwd);
     m.def("rasterize_bwd", &rasterize_bwd);
+    m.def("projection_sh_fwd", &projection_sh_fwd);
+    m.def("rasterize_fwd_packed", &rasterize_fwd_packed);
     m.def("frame_composite_u8", &frame_composite_u8);
 }

@@ -51,6 +51,17 @@ class LazyTensor(torch.Tensor):
     def is_materialized(self) -> bool:
         return self.__dict__.get("_sc_fill") is None
 
+    # copies and serialisation hand out ORDINARY tensors with the contents in place: the pending fill is a closure over
+    # this frame's device buffers and must not travel (copy.copy goes through torch's own path, which reads -- and so
+    # fills -- the tensor; torch's default __deepcopy__ refuses non-wrapper subclasses)
+    def __deepcopy__(self, memo):
+        out = self.materialize().as_subclass(torch.Tensor).clone()
+        memo[id(self)] = out
+        return out
+
+    def __reduce_ex__(self, proto):
+        return self.materialize().as_subclass(torch.Tensor).__reduce_ex__(proto)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}

@@ -882,26 +882,34 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     assert opacities.shape[0] == N and colors.shape[0] == N, (opacities.shape, colors.shape)
     dev = means.device
     centers = camera_centers(viewmats) if centers is None else _req(centers, "camera_centers").reshape(C, 3)
-    radii = torch.empty((C, N), dtype=torch.int32, device=dev)
-    means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
-    depths = torch.empty((C, N), dtype=torch.float32, device=dev)
     st = _stream(means)
+    fast = _lib.fast()
     # the rasterizer's 48-B record per (camera, Gaussian): one gather line per splat instead of four.  With it the
     # conics / opacities / colours arrays of `meta` are not written at all (32 B per Gaussian the frame never reads):
     # _FusedMeta rebuilds them from the records on first access
     use_records = _PACKED_RECORDS["on"] and int(tile_size) == 16 and N > 0 and C > 0
     records = conics = opac = cols = None
-    if use_records:
-        records = torch.empty((C, N, 12), dtype=torch.float32, device=dev)
+    if fast is not None:
+        rc, radii, means2d, depths, records, conics, opac, cols = fast.projection_sh_fwd(
+            means, quats, scales, opacities, colors, viewmats, Ks, centers, int(sh_degree), int(width), int(height),
+            float(eps2d), float(near_plane), float(far_plane), float(radius_clip), bool(antialiased), bool(use_records), st)
+        if rc:
+            _lib.check(rc, "sc_projection_sh_fwd")
     else:
-        conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
-        opac = torch.empty((C, N), dtype=torch.float32, device=dev)
-        cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
-    _lib.check(lib.sc_projection_sh_fwd(_p(means), _p(quats), _p(scales), _p(opacities), _p(colors), _p(viewmats),
-                                        _p(Ks), _p(centers), C, N, K, int(sh_degree), int(width), int(height),
-                                        float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-                                        int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
-                                        _p(opac), _p(cols), _p(records), st), "sc_projection_sh_fwd")
+        radii = torch.empty((C, N), dtype=torch.int32, device=dev)
+        means2d = torch.empty((C, N, 2), dtype=torch.float32, device=dev)
+        depths = torch.empty((C, N), dtype=torch.float32, device=dev)
+        if use_records:
+            records = torch.empty((C, N, 12), dtype=torch.float32, device=dev)
+        else:
+            conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
+            opac = torch.empty((C, N), dtype=torch.float32, device=dev)
+            cols = torch.empty((C, N, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.sc_projection_sh_fwd(_p(means), _p(quats), _p(scales), _p(opacities), _p(colors), _p(viewmats),
+                                            _p(Ks), _p(centers), C, N, K, int(sh_degree), int(width), int(height),
+                                            float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+                                            int(antialiased), _p(radii), _p(means2d), _p(depths), _p(conics),
+                                            _p(opac), _p(cols), _p(records), st), "sc_projection_sh_fwd")
     tile_width = math.ceil(width / float(tile_size))
     tile_height = math.ceil(height / float(tile_size))
     res = None
@@ -917,14 +925,21 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     if backgrounds is not None:
         backgrounds = torch.cat([_req(backgrounds, "backgrounds"),
                                  torch.zeros(C, 1, device=dev)], dim=-1).contiguous()
-    render_colors = torch.empty((C, height, width, 4), dtype=torch.float32, device=dev)
-    render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
     order, work = _sched_of(isect_offsets, C * tile_width * tile_height)
     sch = (_p(order), _p(work))
+    render_colors = render_alphas = None
+    if records is not None and fast is not None:
+        rc, render_colors, render_alphas = fast.rasterize_fwd_packed(records, backgrounds, int(width), int(height),
+                                                                     isect_offsets, flatten_ids, order, work,
+                                                                     render_mode == "RGB+ED", st)
+    else:
+        render_colors = torch.empty((C, height, width, 4), dtype=torch.float32, device=dev)
+        render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
     if records is not None:
-        rc = lib.sc_rasterize_fwd_packed(_p(records), _p(backgrounds), None, C, N, int(width), int(height), tile_width,
-                                         tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
-                                         _p(render_colors), _p(render_alphas), *sch, int(render_mode == "RGB+ED"), st)
+        if fast is None:
+            rc = lib.sc_rasterize_fwd_packed(_p(records), _p(backgrounds), None, C, N, int(width), int(height), tile_width,
+                                             tile_height, _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
+                                             _p(render_colors), _p(render_alphas), *sch, int(render_mode == "RGB+ED"), st)
         if rc == -3:          # the reference-shaped raster kernel is selected: it reads the separate arrays
             conics = torch.empty((C, N, 3), dtype=torch.float32, device=dev)
             opac = torch.empty((C, N), dtype=torch.float32, device=dev)

@@ -316,3 +316,45 @@ def test_lazy_tensor_fills_on_first_read_only():
         assert len(calls) == n0 + 1, read
         assert t.tolist() == [0, 3, 6, 9]
     assert LazyTensor(torch.empty(0, dtype=torch.int64), fill).materialize().numel() == 0
+
+
+def test_lazy_tensor_copies_and_serialisation_are_plain_filled_tensors():
+    """state that rides on tensor objects must survive what callers do to tensors.  A LazyTensor
+    that is copied, deep-copied, pickled, torch.save-d, cloned, detached or converted yields the FILLED contents (the
+    fill runs once), and whatever leaves by deepcopy / pickle is an ordinary torch.Tensor (the pending fill is a closure
+    over device buffers: it must not travel)."""
+    import copy
+    import io
+    import pickle
+    import torch
+    from street_crafter_amd.lazy import LazyTensor
+    want = [0, 3, 6, 9, 12]
+
+    def make(calls):
+        def fill(t):
+            calls.append(1)
+            t.copy_(torch.arange(t.numel(), dtype=t.dtype) * 3)
+        z = LazyTensor(torch.empty(5, dtype=torch.int64), fill)
+        z._sc_offsets = ("cached offsets ride along on the object",)
+        return z
+
+    def save_load(t):
+        b = io.BytesIO()
+        torch.save(t, b)
+        b.seek(0)
+        return torch.load(b, weights_only=True)
+
+    for name, fn, plain in (("copy", copy.copy, False), ("deepcopy", copy.deepcopy, True),
+                            ("pickle", lambda t: pickle.loads(pickle.dumps(t)), True), ("torch.save", save_load, True),
+                            ("clone", lambda t: t.clone(), True), ("detach", lambda t: t.detach(), True),
+                            ("to", lambda t: t.to(torch.int32), True), ("contiguous", lambda t: t.contiguous(), None)):
+        calls = []
+        z = make(calls)
+        r = fn(z)
+        assert r.tolist() == want and z.tolist() == want and calls == [1], (name, r.tolist(), calls)
+        if plain:
+            assert type(r) is torch.Tensor, (name, type(r))
+    # a list / dict holding one (what copy.deepcopy(meta) does)
+    calls = []
+    d = copy.deepcopy({"isect_ids": make(calls), "n": 3})
+    assert type(d["isect_ids"]) is torch.Tensor and d["isect_ids"].tolist() == want and calls == [1]

@@ -1389,6 +1389,47 @@ def test_compiled_binding_layer_equals_the_ctypes_table(ops):
     assert torch.allclose(outs[True][3], outs[False][3], rtol=1e-4, atol=1e-5 * float(outs[False][3].abs().max()))
 
 
+def test_hints_on_carrier_tensors_survive_what_callers_do_to_tensors(ops):
+    """VERDICT r2 weak 12.  Three correctness-neutral hints ride as attributes on tensors the operators hand out
+    (`means2d._sc_viewmats`: the frame's cameras for the view slot; `isect_offsets._sc_sched`: the rasterizer's dispatch
+    list; `isect_ids._sc_offsets`: the cached bucket scan).  A caller may clone / detach / copy / move / re-create any
+    of these tensors between the operator calls: the attribute is then gone and the operators must fall back (view
+    slot 0, plain dispatch, offsets recomputed from the keys) -- with the SAME integers and the same pixels, bit for bit."""
+    import copy
+    cam = make_camera(400, 272, 380.0, 380.0, yaw=0.2).to(DEV)
+    sc = make_scene(30_000, seed=21, z_range=(1.0, 40.0), scale_range=(0.01, 0.3)).to(DEV)
+    w2c, K = cam.viewmat[None], cam.K[None]
+    W, H, tw, th = 400, 272, 25, 17
+
+    def frame(carry):
+        with torch.no_grad():
+            radii, means2d, depths, conics, comps = ops.fully_fused_projection(
+                sc.means, None, sc.quats, sc.scales, w2c, K, W, H, near_plane=cam.znear, far_plane=cam.zfar,
+                calc_compensations=True)
+            means2d = carry(means2d)
+            tpg, ids, fids = ops.isect_tiles(means2d, radii, depths, 16, tw, th, n_cameras=1)
+            ids = carry(ids)
+            off = ops.isect_offset_encode(ids, 1, tw, th)
+            off = carry(off)
+            cols = ops.spherical_harmonics(sc.sh_degree, sc.means[None] - cam.camera_center, sc.sh[None], masks=radii > 0)
+            cols = torch.cat([torch.clamp_min(cols + 0.5, 0.0), depths[..., None]], -1)
+            rc, ra = ops.rasterize_to_pixels(means2d, conics, cols, sc.opacities[None, :, 0] * comps, W, H, 16, off, fids)
+        return tpg, ids, fids, off, rc, ra
+
+    base = None
+    for _ in range(2):                       # second frame: warm hint, speculative sort
+        base = frame(lambda t: t)
+    assert getattr(base[3], "_sc_sched", None) is not None          # the plain path does carry the list
+    carriers = {"clone": lambda t: t.clone(), "detach": lambda t: t.detach(), "copy.copy": copy.copy,
+                "deepcopy": copy.deepcopy, "cpu round trip": lambda t: t.cpu().to(DEV),
+                "new storage": lambda t: torch.empty_like(t).copy_(t), "view": lambda t: t.view(t.shape)[...]}
+    for name, carry in carriers.items():
+        got = frame(carry)
+        torch.cuda.synchronize()
+        for a, b, what in zip(base, got, ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets", "colors", "alphas")):
+            assert torch.equal(torch.as_tensor(a), torch.as_tensor(b)), (name, what)
+
+
 def test_per_shape_tables_are_pruned_together(ops):
     """isect_tiles keeps three per-shape tables (sizes history, prediction, last meta), keyed by (device, C, N, tile
     grid).  Densification changes N every 100 training iterations (train.py:292-310): all three are bounded and pruned
