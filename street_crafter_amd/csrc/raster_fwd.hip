@@ -15,6 +15,7 @@
 
 int g_sc_raster_fwd_variant = 3;
 
+
 namespace {
 
 

@@ -20,6 +20,8 @@ def child(which, lib, frames):
     from street_crafter_amd import _lib
     if lib != "shipped":
         _lib.use_diagnostic_build("" if lib == "diag" else lib)
+    _lib.set_fast_binding(False)       # both arms through the ctypes table (the binding layer is linked to the shipped
+                                       # library only; an operator's event bracket contains its host-side work)
     from harness.caller import render_gaussians
     from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene
     import bench
