@@ -12,7 +12,7 @@ into the uint8 frame the novel-view loop keeps; finished frames are gathered to 
 frames per collective.  Scene tensors are resident in HBM before the timed region.  Every rank keeps `--frames-in-flight`
 (default 2) independent frames in flight, frame f on HIP stream f % 2: the latency-bound
 intersection kernels of one frame run under the VALU-bound rasterizer of the other.  Every 8th timed
-frame is a PROBE frame with HIP events around every operator, which is where `roofline` and
+frame (every 4th when fewer than 40 steps are timed) is a PROBE frame with HIP events around every operator, which is where `roofline` and
 `stage_ms` come from; with two frames in flight a probed kernel shares the GPU with the other
 stream's frame and its time says so (rocprofv3 of the same command sees the same).  The N = 1 run
 therefore also carries `single_stream`: the same K frames one at a time, with the per-kernel times
@@ -429,6 +429,8 @@ def run_rank(args):
         if not selftest:
             torch.cuda.synchronize(dev)
 
+    probe_every = 8 if args.steps >= 40 else 4       # (the driver's --steps 20: five probe frames instead of three)
+
     def run_steps(first, last, timed, g, step_fn, n_str=n_streams, rec=None):
         """steps [first, last): frame s on stream s % n_str; with a recorder, every 8th timed step is a probe frame
         with per-operator HIP events (no draining: with n_str > 1 a probed kernel shares the GPU with the other
@@ -436,7 +438,7 @@ def run_rank(args):
         strs = streams[:n_str] if (streams is not None and n_str > 1) else None
         for s in range(first, last):
             r = s - first          # round number of this run (the gatherer is reset between runs)
-            probe = rec is not None and timed and ((s - first) % 8 == 0) and not selftest
+            probe = rec is not None and timed and ((s - first) % probe_every == 0) and not selftest
             ctx = torch.cuda.stream(strs[s % n_str]) if strs is not None else None
             if ctx is not None:
                 ctx.__enter__()
@@ -671,24 +673,6 @@ def run_rank(args):
                 del sc_v, cams_v
         if "knn" not in skip:
             secondary["knn"] = knn_line(dev)
-        if "forced_gather" not in skip and not args.force_gather:
-            # the RCCL transport on the one GPU of this box: a world of ONE through the real staging ring + async
-            # dist.gather (VERDICT r2 missing 1).  Not a scaling number -- there is none until an 8-GPU node runs this.
-            try:
-                init_world1(dev)
-                gf = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch, force_collective=True)
-                el, _, fr = timed_run(render_into, gf, n_streams)
-                secondary["forced_gather_world1"] = {
-                    "value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
-                    "frames_in_flight": n_streams, "backend": dist.get_backend(), "collectives": gf.stats["gathers"],
-                    "frames_per_collective": gf.batch,
-                    "frames_identical_to_headline": bool(all(torch.equal(a, b) for a, b in zip(frames, fr))),
-                    "what": "the headline loop with init_process_group('nccl', world_size=1) and the world == 1 short cut of "
-                            "the gatherer disabled: every frame goes through the staging ring and an async dist.gather on "
-                            "RCCL's stream (at one rank the collective is a device copy; no bytes cross xGMI)"}
-                del fr, gf
-            except Exception as e:          # noqa: BLE001  (a box whose RCCL cannot initialise must not cost the bench line)
-                secondary["forced_gather_world1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if "train" not in skip and not args.scene_ply:
             # SURVEY 8(d) secondary: forward + backward steps/s at the reference's training resolution
             # (camera_utils.py:150-152: Waymo frames are trained at 1600 px width), L1 loss, all five parameter
@@ -759,6 +743,26 @@ def run_rank(args):
                 "device_ms_operators_sum": sum(st_ms.values()),
                 "_traffic_key": tkey, "_bwd_bytes": bwd_bytes, "_bwd_ms": bwd_ms, "_pairs": 256 * I_t}
             del tscene, tparams, target, o_t
+
+    if world == 1 and not selftest and "forced_gather" not in skip and not args.force_gather:
+        # (last of the secondary measurements: RCCL's threads exist from here on)
+        # the RCCL transport on the one GPU of this box: a world of ONE through the real staging ring + async
+        # dist.gather (VERDICT r2 missing 1).  Not a scaling number -- there is none until an 8-GPU node runs this.
+        try:
+            init_world1(dev)
+            gf = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch, force_collective=True)
+            el, _, fr = timed_run(render_into, gf, n_streams)
+            secondary["forced_gather_world1"] = {
+                "value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
+                "frames_in_flight": n_streams, "backend": dist.get_backend(), "collectives": gf.stats["gathers"],
+                "frames_per_collective": gf.batch,
+                "frames_identical_to_headline": bool(all(torch.equal(a, b) for a, b in zip(frames, fr))),
+                "what": "the headline loop with init_process_group('nccl', world_size=1) and the world == 1 short cut of "
+                        "the gatherer disabled: every frame goes through the staging ring and an async dist.gather on "
+                        "RCCL's stream (at one rank the collective is a device copy; no bytes cross xGMI)"}
+            del fr, gf
+        except Exception as e:          # noqa: BLE001  (a box whose RCCL cannot initialise must not cost the bench line)
+            secondary["forced_gather_world1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- per-operator device time from the probe frames' HIP events ----------------------------------------
     torch.cuda.synchronize(dev)

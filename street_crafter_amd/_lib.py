@@ -15,6 +15,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "lib", "libstreet_crafter_hip_diag.so")
 
 _lib = None
 _path = LIB_PATH
+_lock = __import__("threading").Lock()      # two host threads may make the first call at the same time
 
 
 def use_diagnostic_build(tag: str = ""):
@@ -107,6 +108,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    with _lock:
+        return _load_locked()
+
+
+def _load_locked():
+    global _lib
+    if _lib is not None:
+        return _lib
     if not os.path.exists(_path):
         raise ImportError(
             f"street_crafter_amd: HIP library not built ({_path} missing). "
@@ -135,6 +144,14 @@ def fast():
         return None
     if _fast is None:
         load()
+        with _lock:
+            return _fast_locked()
+    return _fast
+
+
+def _fast_locked():
+    global _fast
+    if _fast is None:
         if not os.path.exists(FAST_PATH):
             raise ImportError(f"street_crafter_amd: binding layer not built ({FAST_PATH} missing). "
                               "Build it with `python -m street_crafter_amd.build`.")
