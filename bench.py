@@ -666,12 +666,28 @@ def run_rank(args):
                                 "sequence -> uint8 frame, two frames in flight (the headline's timing)", rec=rec_v,
                                 shape=(vh, vw, 3))
                 d1, _ = measure(variant_into, 1, "same, one frame in flight", shape=(vh, vw, 3))
+                op_v = sc_v.opacities[:, 0].contiguous()
+
+                def variant_fused_into(s, out, events=None, intermediates=False, sc_v=sc_v, cams_v=cams_v, op_v=op_v):
+                    cam = cams_v[s]
+                    with torch.no_grad():
+                        rc, _, _ = rasterization(sc_v.means, sc_v.quats, sc_v.scales, op_v, sc_v.sh, cam.viewmat[None],
+                                                 cam.K[None], cam.width, cam.height, near_plane=cam.znear, far_plane=cam.zfar,
+                                                 sh_degree=sc_v.sh_degree, render_mode="RGB+ED",
+                                                 rasterize_mode="antialiased", camera_centers_=cam.camera_center[None])
+                        to_uint8_frame(rc[0, ..., :3].permute(2, 0, 1), out=out)
+
+                df2, _ = measure(variant_fused_into, 2, "the same frames through the fused rasterization(), two in flight",
+                                 shape=(vh, vw, 3))
+                df1, _ = measure(variant_fused_into, 1, "same, one in flight", shape=(vh, vw, 3))
                 torch.cuda.synchronize(dev)
                 Kv, Pv, Tv = (vdeg + 1) ** 2, vw * vh, math.ceil(vw / 16) * math.ceil(vh / 16)
                 I_v = sum(rec_v["n_isects"]) / max(len(rec_v["n_isects"]), 1)
                 b_v = algorithmic_bytes(vn, int(I_v), vw, vh, 16, Kv)
                 d2["single_stream"] = {"value": d1["value"], "ms_per_step": d1["ms_per_step"], "frames_in_flight": 1,
                                        "frac_of_hbm_roofline_wall": d1["value"] / (HBM_PEAK / b_v)}
+                d2["fused_rasterization"] = {"value": df2["value"], "unit": "frames/s", "frames_in_flight": 2,
+                                             "single_stream": df1["value"], "what": df2["what"]}
                 d2["n_isects_mean"] = I_v
                 d2["frame_roofline"] = {"algorithmic_bytes_per_frame": b_v, "hbm_bound_fps_per_gpu": HBM_PEAK / b_v,
                                         "frac_of_hbm_roofline_wall": d2["value"] / (HBM_PEAK / b_v),

@@ -358,3 +358,39 @@ def test_lazy_tensor_copies_and_serialisation_are_plain_filled_tensors():
     calls = []
     d = copy.deepcopy({"isect_ids": make(calls), "n": 3})
     assert type(d["isect_ids"]) is torch.Tensor and d["isect_ids"].tolist() == want and calls == [1]
+
+
+def test_compiled_binding_layer_loads_and_refuses_cpu_tensors(lib):
+    """csrc/binding.cpp -> lib/_sc_fast.so: the default host path.  It must be the same build as the library (version
+    string), export one entry per hot operator call, and refuse tensors that are not on a HIP device before anything
+    is launched; set_fast_binding() switches to the ctypes table and back; the diagnostic build never gets it."""
+    import torch
+    from street_crafter_amd import _lib
+    fast = _lib.fast()
+    assert fast is not None and os.path.exists(_lib.FAST_PATH)
+    assert fast.abi_version().encode() == lib.sc_version()
+    for name in ("projection_fwd", "projection_bwd", "isect_bin_count", "isect_bin_sort", "wait_i64", "sh_fwd", "sh_bwd",
+                 "rasterize_fwd", "rasterize_bwd", "projection_sh_fwd", "rasterize_fwd_packed", "frame_composite_u8"):
+        assert callable(getattr(fast, name)), name
+    n = 8
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="HIP device"):
+        fast.projection_fwd(z(n, 3), z(n, 4), z(n, 3), torch.eye(4)[None], torch.eye(3)[None], 64, 64, 0.3, 0.01, 1e10,
+                            0.0, True, 0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        fast.sh_fwd(1, z(1, n, 3), z(1, n, 4, 3), None, 0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        fast.isect_bin_count(z(1, n, 2), z(1, n, dtype=torch.int32), z(1, n), 16, 4, 4, None, None, None, False, 0, 1, 0)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        fast.rasterize_fwd(z(1, n, 2), z(1, n, 3), z(1, n, 3), z(1, n), None, None, 64, 64, 16,
+                           z(1, 4, 4, dtype=torch.int32), z(0, dtype=torch.int32), False, None, None, 0)
+    # host-side wait through the binding: same contract as sc_wait_i64 (0 = arrived, 1 = timed out)
+    word = torch.zeros(1, dtype=torch.int64)
+    word[0] = 5
+    assert fast.wait_i64(word.data_ptr(), 5, 1000) == 0 and fast.wait_i64(word.data_ptr(), 6, 2000) == 1
+    prev = _lib.set_fast_binding(False)
+    try:
+        assert prev is True and _lib.fast() is None
+    finally:
+        _lib.set_fast_binding(prev)
+    assert _lib.fast() is fast
