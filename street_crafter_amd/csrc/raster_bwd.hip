@@ -236,7 +236,7 @@ __device__ __forceinline__ void raster_bwd_item(
     float* __restrict__ v_means2d_abs, float* __restrict__ v_means2d, float* __restrict__ v_conics,
     float* __restrict__ v_colors, float* __restrict__ v_opacities, int tflat, int sub,
     float4* xyoa_s, float4* bck_s, float4* col_s) {
-    constexpr int SB = 2;
+    constexpr int SB = 2;      // (one per lane, which pays in the forward, changes nothing here: 285.6 vs 287.6 us)
     constexpr int B = 64 * SB;
     if (tile_masks && !tile_masks[tflat]) return;
     const int tiles_per_cam = tile_width * tile_height;

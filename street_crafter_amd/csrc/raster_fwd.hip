@@ -18,6 +18,11 @@ int g_sc_raster_fwd_variant = 3;
 
 namespace {
 
+#ifdef SC_RASTER_SB
+constexpr int RASTER_SB = SC_RASTER_SB;     // (experiment builds: tools/ab_lib.py)
+#else
+constexpr int RASTER_SB = 1;                // splats staged per lane per batch of the wave kernel (see raster_item)
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -152,7 +157,13 @@ __device__ __forceinline__ void raster_item(
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
     int32_t* __restrict__ last_ids, int tflat, int sub,
     float4* xyoa_s, float4* bck_s, float4* col_s, int32_t* __restrict__ tile_work SC_DIAG_PARAM(dbg)) {
-    constexpr int SB = 2;                 // splats staged per lane per batch
+    // Splats staged per lane per batch.  ONE (batches of 64) since round 3: the kernel's second bound, beside VALU issue,
+    // is the rate of its parameter gathers (4 random sectors per list entry: with the blend loop compiled out S-1M's
+    // whole lists take 686 us, i.e. ~35 us per million entries walked), and a tile that stops after
+    // ~250 entries throws away what it staged beyond that point: on average half a batch plus the batch in flight.
+    // Batches of 64 halve that: S-1M 142 -> 134 us, sky 107 -> 100, S-100k 135 -> 132, street scene unchanged
+    // (profiles/r03_raster_batch_ab.txt).
+    constexpr int SB = RASTER_SB;
     constexpr int B = 64 * SB;            // batch size
     constexpr int NP = NSUB == 1 ? 2 : 1; // pixel PAIRS per lane
     constexpr int PPL = NSUB == 1 ? 4 : (NSUB == 2 ? 2 : 1);   // live pixels per lane
@@ -238,6 +249,10 @@ __device__ __forceinline__ void raster_item(
     float4 p_col[SB];
     bool p_live[SB];
     int g_next[SB];
+#ifdef SC_EXP_GATE
+    int g_cur[SB];
+    bool have_params = true;
+#endif
     auto load_splat = [&](int g, int j) {
         if (PACKED) {
             const float4* rec = reinterpret_cast<const float4*>(means2d) + (int64_t)g * 3;
@@ -273,8 +288,16 @@ __device__ __forceinline__ void raster_item(
 
     for (int b = 0; b < num_batches; ++b) {
         if (all_done()) break;
+#ifdef SC_EXP_GATE
+        if (!have_params) {               // the prefetch of this batch's parameters was withheld (see below): fetch them now
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+                if (p_live[j]) load_splat(g_cur[j], j);
+            have_params = true;
+        }
+#endif
         const int batch_start = range_start + B * b;
-        walked += 8;                      // a staged batch (gather + cull) weighs about 8 blend iterations
+        walked += 4 * SB;                 // a staged batch of 128 (gather + cull) weighs about 8 blend iterations
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
         int bsz = 0;
         __syncthreads();   // single-wave workgroup: orders the previous batch's LDS reads vs these writes
@@ -299,6 +322,30 @@ __device__ __forceinline__ void raster_item(
         }
         __syncthreads();
         // ---- next batch's parameters and the ids after that go in flight ---------------------------
+#ifdef SC_EXP_GATE
+        {
+            // largest transmittance among the tile's live pixels BEFORE this batch blends: a tile whose every pixel is
+            // already below the gate will most likely finish inside this batch, and the next batch's parameter gathers
+            // (4 random sectors per entry, the kernel's real bound) would be thrown away
+            float tm = 0.f;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                tm = fmaxf(tm, __float_as_int(pxp[p].x) == 0x7f800000 ? 0.f : T2[p].x);
+                tm = fmaxf(tm, __float_as_int(pxp[p].y) == 0x7f800000 ? 0.f : T2[p].y);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
+            have_params = tm >= (float)(SC_EXP_GATE);
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+            g_cur[j] = g_next[j];
+            p_live[j] = g_cur[j] >= 0;
+            if (p_live[j] && have_params) load_splat(g_cur[j], j);
+            const int idx2 = batch_start + 2 * B + j * 64 + lane;
+            g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             p_live[j] = g_next[j] >= 0;
@@ -306,6 +353,7 @@ __device__ __forceinline__ void raster_item(
             const int idx2 = batch_start + 2 * B + j * 64 + lane;
             g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
         }
+#endif
         // ---- blend ---------------------------------------------------------------------------------
         if (SC_DIAG_BIT(dbg, 1)) bsz = 0;      // diagnostic build only: price the kernel without its blend loop
         if (bsz > 0) {
@@ -357,14 +405,16 @@ __device__ __forceinline__ void raster_item(
                 a1 = xyoa_s[t + 1]; b1 = bck_s[t + 1]; c1 = col_s[t + 1];
                 // The scheduler sinks these three LDS reads BELOW the blend of the current record (fewer live
                 // registers), which puts their latency in front of every iteration (ISA of round 2: ds_read x3 then
-                // s_waitcnt lgkmcnt(2) at the loop top).  Pinning them above costs 10 VGPRs (82 -> 92: still 5 waves
-                // per SIMD) and gives -1 us on S-1M, -2..-6 us on the street scene (tools/ab_lib.py,
-                // profiles/r03_raster_prefetch_ab.txt).  Not with TRACK: 98 VGPRs there -> 4 waves per SIMD, +22 us.
-                if constexpr (!TRACK) __builtin_amdgcn_sched_barrier(0);
+                // s_waitcnt lgkmcnt(2) at the loop top).  Pinning them above costs 10 VGPRs and gives -1 us on S-1M,
+                // -2..-6 us on the street scene (tools/ab_lib.py, profiles/r03_raster_prefetch_ab.txt).  With two
+                // splats staged per lane the variant WITH last_ids then needed 98 VGPRs (4 waves per SIMD, +22 us) and
+                // went without; with one per lane (batches of 64) every variant fits 82 and the training forward
+                // gains 18 us from the pin (131 -> 113 us, profiles/r03_raster_batch_ab.txt).
+                __builtin_amdgcn_sched_barrier(0);
                 blend(a0, b0, c0);
                 if (++t >= bsz) break;
                 a0 = xyoa_s[t + 1]; b0 = bck_s[t + 1]; c0 = col_s[t + 1];
-                if constexpr (!TRACK) __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);
                 blend(a1, b1, c1);
                 if (all_done()) { walked += t + 1 - bsz; break; }
                 if (++t >= bsz) break;
@@ -408,7 +458,7 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     float* __restrict__ render_colors, float* __restrict__ render_alphas,
     int32_t* __restrict__ last_ids, int map_mode, const int32_t* __restrict__ order,
     int32_t* __restrict__ tile_work SC_DIAG_PARAM(dbg)) {
-    constexpr int B = 128;
+    constexpr int B = 64 * RASTER_SB;
     __shared__ float4 xyoa_s[B + 1];      // mx, my, opac, conic.a      (+1: the loop prefetches t+1)
     __shared__ float4 bck_s[B + 1];       // conic.b, conic.c, sorted index (int bits), -
     __shared__ float4 col_s[B + 1];       // colour channels

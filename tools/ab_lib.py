@@ -3,7 +3,7 @@
 box in one gpurun call.  The two libraries cannot live in one process (same symbols), so each arm is a child process;
 arms alternate (A B A B ...) and the medians over all rounds are printed.
 
-    python tools/ab_lib.py [s1m|street1m|sky|train] [rounds] [frames] [arm,arm,...]
+    python tools/ab_lib.py [s1m|s100k|street1m|sky|train] [rounds] [frames] [arm,arm,...]
     (arms: "diag" or the SC_DIAG_TAG names of experiment builds: lib/libstreet_crafter_hip_diag_<tag>.so)
 """
 import json
@@ -28,7 +28,7 @@ def child(which, lib, frames):
     dev = "cuda"
     train = which == "train"
     W, H = (1600, 1066) if train else (1920, 1280)
-    sc = {"s1m": lambda: make_scene(1_000_000), "train": lambda: make_scene(1_000_000),
+    sc = {"s1m": lambda: make_scene(1_000_000), "train": lambda: make_scene(1_000_000), "s100k": lambda: make_scene(100_000),
           "street1m": lambda: make_street_scene(1_000_000)[0], "sky": lambda: make_street_scene(1_000_000)[1]}[which]().to(dev)
     ev = {}
     if train:
