@@ -164,7 +164,8 @@ __device__ __forceinline__ void raster_item(
     // Batches of 64 halve that: S-1M 142 -> 134 us, sky 107 -> 100, S-100k 135 -> 132, street scene unchanged
     // (profiles/r03_raster_batch_ab.txt).
     constexpr int SB = RASTER_SB;
-    constexpr int B = 64 * SB;            // batch size
+    constexpr int B = 64 * SB;            // batch size (half-wave batches of 32 were measured too: +6 / +30 / +7 us on
+                                          // S-1M / street / S-100k, profiles/r03_raster_batch_ab.txt)
     constexpr int NP = NSUB == 1 ? 2 : 1; // pixel PAIRS per lane
     constexpr int PPL = NSUB == 1 ? 4 : (NSUB == 2 ? 2 : 1);   // live pixels per lane
     constexpr int ROWS = 16 / NSUB;       // rows of the tile this wave covers
@@ -249,10 +250,6 @@ __device__ __forceinline__ void raster_item(
     float4 p_col[SB];
     bool p_live[SB];
     int g_next[SB];
-#ifdef SC_EXP_GATE
-    int g_cur[SB];
-    bool have_params = true;
-#endif
     auto load_splat = [&](int g, int j) {
         if (PACKED) {
             const float4* rec = reinterpret_cast<const float4*>(means2d) + (int64_t)g * 3;
@@ -288,14 +285,6 @@ __device__ __forceinline__ void raster_item(
 
     for (int b = 0; b < num_batches; ++b) {
         if (all_done()) break;
-#ifdef SC_EXP_GATE
-        if (!have_params) {               // the prefetch of this batch's parameters was withheld (see below): fetch them now
-#pragma unroll
-            for (int j = 0; j < SB; ++j)
-                if (p_live[j]) load_splat(g_cur[j], j);
-            have_params = true;
-        }
-#endif
         const int batch_start = range_start + B * b;
         walked += 4 * SB;                 // a staged batch of 128 (gather + cull) weighs about 8 blend iterations
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
@@ -322,30 +311,6 @@ __device__ __forceinline__ void raster_item(
         }
         __syncthreads();
         // ---- next batch's parameters and the ids after that go in flight ---------------------------
-#ifdef SC_EXP_GATE
-        {
-            // largest transmittance among the tile's live pixels BEFORE this batch blends: a tile whose every pixel is
-            // already below the gate will most likely finish inside this batch, and the next batch's parameter gathers
-            // (4 random sectors per entry, the kernel's real bound) would be thrown away
-            float tm = 0.f;
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                tm = fmaxf(tm, __float_as_int(pxp[p].x) == 0x7f800000 ? 0.f : T2[p].x);
-                tm = fmaxf(tm, __float_as_int(pxp[p].y) == 0x7f800000 ? 0.f : T2[p].y);
-            }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o, 64));
-            have_params = tm >= (float)(SC_EXP_GATE);
-        }
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
-            g_cur[j] = g_next[j];
-            p_live[j] = g_cur[j] >= 0;
-            if (p_live[j] && have_params) load_splat(g_cur[j], j);
-            const int idx2 = batch_start + 2 * B + j * 64 + lane;
-            g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
-        }
-#else
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
             p_live[j] = g_next[j] >= 0;
@@ -353,7 +318,6 @@ __device__ __forceinline__ void raster_item(
             const int idx2 = batch_start + 2 * B + j * 64 + lane;
             g_next[j] = (idx2 < range_end) ? sc_safe_id(flatten_ids[idx2], N) : -1;
         }
-#endif
         // ---- blend ---------------------------------------------------------------------------------
         if (SC_DIAG_BIT(dbg, 1)) bsz = 0;      // diagnostic build only: price the kernel without its blend loop
         if (bsz > 0) {
