@@ -12,7 +12,6 @@ from __future__ import annotations
 import collections
 import math
 import threading
-import time
 from typing import Optional, Tuple
 
 import torch
