@@ -147,6 +147,40 @@ __global__ void raster_fwd_ref_kernel(
 // PACKED: `means2d` points to one 48-B record per Gaussian, (x, y, conic a, b | conic c, opacity, colour 0, 1 |
 // colour 2, 3, -, -), written by projection_sh_fwd_kernel for the fused forward: one gather line per splat instead of four.
 // ED: the "RGB+ED" epilogue (sc_rasterize_fwd_ed; CDIM == 4): channel 3 leaves as depth sum / max(alpha, 1e-10).
+#ifdef SC_DIAG
+// Diagnostic build only ("debug1" bit 4; tools/exp_raster_phases.py): where the waves of the wave kernel spend their
+// lives, in shader-clock cycles summed over all waves: [0] entry to exit, [1] issuing the next batch's gathers,
+// [2] cull + compaction, [3] blend loop, [4] waves, [5] batches, [6] records kept by the cull, [7] entry to the first
+// batch's parameters having arrived, [8] entry to exit in ticks of the constant 100 MHz clock.  (The wait for a batch's parameters at its top measured 72 cycles: the prefetch
+// hides the gathers completely, except the first batch's.)
+// One row per wave (tile x half): 90 k atomics on eight shared counters made the kernel four times slower.
+constexpr int SC_PHASE_ROWS = 65536;
+__device__ unsigned long long g_sc_phase_cycles[SC_PHASE_ROWS][10];
+__global__ void phase_sum_kernel(unsigned long long* out8, int reset) {
+    __shared__ unsigned long long acc[10];
+    if (threadIdx.x < 10) acc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int r = threadIdx.x; r < SC_PHASE_ROWS; r += blockDim.x)
+        for (int k = 0; k < 10; ++k) {
+            const unsigned long long v = g_sc_phase_cycles[r][k];
+            if (v) atomicAdd(&acc[k], v);
+            if (reset) g_sc_phase_cycles[r][k] = 0;
+        }
+    __syncthreads();
+    if (threadIdx.x < 10) out8[threadIdx.x] = acc[threadIdx.x];
+}
+extern "C" int sc_diag_phase_cycles(unsigned long long* out8, int reset) {
+    unsigned long long* d = nullptr;
+    hipError_t e = hipMalloc(&d, 80);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(phase_sum_kernel, dim3(1), dim3(1024), 0, 0, d, reset);
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess && out8) e = hipMemcpy(out8, d, 80, hipMemcpyDeviceToHost);      // (ten words)
+    hipFree(d);
+    return (int)e;
+}
+#endif
+
 template <int CDIM, bool TRACK, int NSUB, bool PACKED = false, bool ED = false>
 __device__ __forceinline__ void raster_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
@@ -203,6 +237,9 @@ __device__ __forceinline__ void raster_item(
         if (tile_work && lane == 0) tile_work[tflat] = 0;
         return;
     }
+    const bool prof = SC_DIAG_BIT(dbg, 4);
+    const unsigned long long pc_begin = SC_DIAG_CLOCK(prof), pr_begin = SC_DIAG_REALTIME(prof);
+    unsigned long long pc_stage = 0, pc_issue = 0, pc_blend = 0, pc_first = 0, pc_batches = 0, pc_splats = 0;
     int range_start, range_end;
     sc_tile_range(isect_offsets, tflat, total_tiles, n_isects, range_start, range_end);
     const int num_batches = (range_end - range_start + B - 1) / B;
@@ -286,6 +323,10 @@ __device__ __forceinline__ void raster_item(
     for (int b = 0; b < num_batches; ++b) {
         if (all_done()) break;
         const int batch_start = range_start + B * b;
+        const unsigned long long pc0 = SC_DIAG_CLOCK(prof);
+        SC_DIAG_DRAIN(prof);
+        const unsigned long long pcw = SC_DIAG_CLOCK(prof);
+        if (prof && b == 0) pc_first = pcw - pc_begin;
         walked += 4 * SB;                 // a staged batch of 128 (gather + cull) weighs about 8 blend iterations
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
         int bsz = 0;
@@ -310,6 +351,7 @@ __device__ __forceinline__ void raster_item(
             bsz += __popcll(m);
         }
         __syncthreads();
+        const unsigned long long pc1 = SC_DIAG_CLOCK(prof);
         // ---- next batch's parameters and the ids after that go in flight ---------------------------
 #pragma unroll
         for (int j = 0; j < SB; ++j) {
@@ -320,6 +362,7 @@ __device__ __forceinline__ void raster_item(
         }
         // ---- blend ---------------------------------------------------------------------------------
         if (SC_DIAG_BIT(dbg, 1)) bsz = 0;      // diagnostic build only: price the kernel without its blend loop
+        const unsigned long long pc2 = SC_DIAG_CLOCK(prof);
         if (bsz > 0) {
             // one blended splat: a = (mx, my, log2 op, B2), bc = (A2, C2, sorted index, -), c = colour
             auto blend = [&](const float4& a, const float4& bc, const float4& c) {
@@ -385,6 +428,10 @@ __device__ __forceinline__ void raster_item(
             }
             walked += bsz;
         }
+        if (prof) {
+            const unsigned long long pc3 = SC_DIAG_CLOCK(prof);
+            pc_stage += pc2 - pc1; pc_issue += pc1 - pcw; pc_blend += pc3 - pc2; pc_batches += 1; pc_splats += (unsigned long long)bsz;
+        }
     }
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
@@ -410,6 +457,16 @@ __device__ __forceinline__ void raster_item(
         if (TRACK) last_ids[pix] = cur[k];
     }
     if (tile_work && lane == 0) tile_work[tflat] = walked;     // halves: the later finisher's count stands
+#ifdef SC_DIAG
+    const int prow = tflat * 2 + (NSUB == 1 ? 0 : sub);
+    if (prof && lane == 0 && prow < SC_PHASE_ROWS) {
+        const unsigned long long pc_end = SC_DIAG_CLOCK(prof);
+        unsigned long long* row = g_sc_phase_cycles[prow];      // (+=: the frames of a run accumulate)
+        row[0] += pc_end - pc_begin; row[1] += pc_stage; row[2] += pc_issue; row[3] += pc_blend;
+        row[4] += 1ull; row[5] += pc_batches; row[6] += pc_splats; row[7] += pc_first;
+        row[8] += SC_DIAG_REALTIME(prof) - pr_begin;      // the same lifetime in 100 MHz ticks: [0] / [8] = shader clock / 100 MHz
+    }
+#endif
 }
 
 template <int CDIM, bool TRACK, bool PACKED = false, bool ED = false>

@@ -33,10 +33,28 @@ extern int g_sc_debug[4];
 #define SC_DIAG_PARAM(name) , int name            /* trailing kernel / function parameter */
 #define SC_DIAG_ARG(value) , (value)              /* ... and its argument at the call / launch site */
 #define SC_DIAG_BIT(name, mask) (((name) & (mask)) != 0)
+/* shader clock for phase timing: raw s_memtime (the builtin makes the compiler drain every outstanding load first, which
+   serialises exactly the prefetches whose overlap is being measured); SC_DIAG_DRAIN waits for the loads explicitly */
+__device__ __forceinline__ unsigned long long sc_diag_clock_raw() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define SC_DIAG_CLOCK(on) ((on) ? sc_diag_clock_raw() : 0ull)
+__device__ __forceinline__ unsigned long long sc_diag_realtime_raw() {      /* constant 100 MHz */
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define SC_DIAG_REALTIME(on) ((on) ? sc_diag_realtime_raw() : 0ull)
+#define SC_DIAG_DRAIN(on) do { if (on) asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); } while (0)
 #else
 #define SC_DIAG_PARAM(name)
 #define SC_DIAG_ARG(value)
 #define SC_DIAG_BIT(name, mask) false
+#define SC_DIAG_CLOCK(on) 0ull
+#define SC_DIAG_REALTIME(on) 0ull
+#define SC_DIAG_DRAIN(on) do { } while (0)
 #endif
 extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
 // VIEW SLOTS: the rasterizer's work hint is kept per VIEW (a street rig renders front / front-left / front-right in
