@@ -604,6 +604,10 @@ def run_rank(args):
             d2, fr2 = measure(two_pass_fused_into, 1, "same, each pass through the fused rasterization()")
             d["fused_rasterization"] = d2
             d["fused_frames_identical"] = bool(all(torch.equal(a, b) for a, b in zip(fr, fr2)))
+            if "two_in_flight" not in skip:
+                # the headline's timing (two frames in flight on two HIP streams) for render.py's real frame
+                d["two_frames_in_flight"], _ = measure(two_pass_into, 2, "same frames, two in flight", fr)
+                d2["two_frames_in_flight"], _ = measure(two_pass_fused_into, 2, "same frames, two in flight", fr2)
             secondary["two_pass_frame"] = d
             del fr, fr2, sky
         if "street" not in skip and not args.scene_ply:
