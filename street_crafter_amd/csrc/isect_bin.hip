@@ -745,6 +745,12 @@ constexpr int SS_WAVES = SS_THREADS / 64;
 constexpr int SS_MAX_CAP = 3584;                 // records one workgroup sorts in LDS (3 workgroups per CU); longer buckets are SPLIT first
 constexpr int SS_RPT = SS_MAX_CAP / SS_THREADS;  // records per thread held in registers (7)
 constexpr int SS_NC = SS_THREADS;                // coarse bins of the two-level interpolation (one per thread)
+// Frames whose buckets are all small (S-100k: ~290 records per super-tile; a set of actors) are sorted by 128-thread
+// workgroups: the 512-thread form ran 8 waves through every phase for half a record per thread (30 us at S-100k for
+// 0.7 M records, 2400 workgroups in 2.3 rounds); two waves per bucket are all resident at once.
+constexpr int SS_SMALL_THREADS = 128;
+constexpr int SS_SMALL_RPT = 8;
+constexpr int SS_SMALL_CAP = SS_SMALL_THREADS * SS_SMALL_RPT;      // 1024 records
 constexpr int64_t BIG_MAX_SUPER = 220000;        // largest super-tile the split path takes (limits its LDS tables)
 
 // A SEGMENT is what one workgroup sorts: a whole super-tile's bucket, or one depth range of an oversized one.
@@ -835,16 +841,17 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     }
 }
 
-// LDS of the sort: [B: cap u64][order: cap u16][boff: cap + 2 u32][coarse: SS_NC u32][table][totals 4 u32]
+// LDS of the sort: [B: cap u64][order: cap u16][boff: cap + 2 u32][coarse: NC u32][table][totals 4 u32]
 // (14 B per record + 2.6 KiB: three workgroups per CU up to cap = 3584)
-__host__ __device__ inline size_t sort_lds_bytes(int cap) {
-    const size_t table = (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64;
-    return (size_t)cap * 10 + (size_t)((cap + 4) & ~1) * 4 + (size_t)SS_NC * 4 + table + 16;
+// (`threads` = the workgroup size of the instantiation: SS_THREADS, or SS_SMALL_THREADS for frames of small buckets)
+__host__ __device__ inline size_t sort_lds_bytes(int cap, int threads = SS_THREADS) {
+    const size_t table = (size_t)((cap + threads - 1) / threads + 1) * (threads / 64) * 8 + 64;
+    return (size_t)cap * 10 + (size_t)((cap + 4) & ~1) * 4 + (size_t)threads * 4 + table + 16;
 }
 
 // Two-level interpolation sort of one segment (n <= cap <= SS_MAX_CAP records) on the 60-bit key
 // (depth bits, flat id), then the stable per-tile emit.
-//   level 1: SS_NC coarse bins by a MONOTONE linear map of the key over [lo, hi] (double precision: the
+//   level 1: NC coarse bins by a MONOTONE linear map of the key over [lo, hi] (double precision: the
 //            map must be exactly non-decreasing in the key -- a correctly rounded u64 -> f64 conversion,
 //            one multiply, one truncation);
 //   level 2: a coarse bin that received c records is cut into c FINE buckets by the same map restricted to
@@ -855,36 +862,38 @@ __host__ __device__ inline size_t sort_lds_bytes(int cap) {
 //   counting sort into the n fine buckets, then every record is ranked inside its bucket by counting
 //   smaller keys.  Whatever the distribution the result is the exact order; only the cost of the ranking
 //   loop depends on it (equal depths are separated by the id bits of the key).
+template <int THREADS, int RPT>
 __device__ __forceinline__ void sort_segment(
     const uint2* __restrict__ recs, int n, int sb, const int* tb, int cap, const Geo& g,
     const int32_t* __restrict__ offsets, int n_tbuckets, int64_t n_isects, int tile_bits,
     unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out
     SC_DIAG_PARAM(dbg)) {
+    constexpr int WAVES = THREADS / 64, NC = THREADS;          // coarse bins: one per thread
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
     unsigned short* order = reinterpret_cast<unsigned short*>(B + cap);      // cap is a multiple of 256
     unsigned* boff = reinterpret_cast<unsigned*>(order + cap);              // [n + 1] fine-bucket counters
-    unsigned* coarse = boff + ((cap + 4) & ~1);       // [SS_NC] count in the low, first fine bucket in the high half
-    unsigned long long* table = reinterpret_cast<unsigned long long*>(coarse + SS_NC);
+    unsigned* coarse = boff + ((cap + 4) & ~1);       // [NC] count in the low, first fine bucket in the high half
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(coarse + NC);
     unsigned* totals = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(table) +
-                                                   (size_t)((cap + SS_THREADS - 1) / SS_THREADS + 1) * SS_WAVES * 8 + 64);
-    __shared__ unsigned long long red_lo[SS_WAVES], red_hi[SS_WAVES];
-    __shared__ unsigned red_sum[SS_WAVES];
+                                                   (size_t)((cap + THREADS - 1) / THREADS + 1) * WAVES * 8 + 64);
+    __shared__ unsigned long long red_lo[WAVES], red_hi[WAVES];
+    __shared__ unsigned red_sum[WAVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
-    for (int i = t; i <= n; i += SS_THREADS) boff[i] = 0;
+    for (int i = t; i <= n; i += THREADS) boff[i] = 0;
     coarse[t] = 0u;
     // the segment's records are read from global memory ONCE, all loads of a thread in flight together,
     // and stay in registers through the min/max, both counting passes and the scatter
-    uint2 rec[SS_RPT];
+    uint2 rec[RPT];
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        const int i = t + k * SS_THREADS;
+    for (int k = 0; k < RPT; ++k) {
+        const int i = t + k * THREADS;
         rec[k] = (i < n) ? recs[i] : make_uint2(0u, 0u);
     }
     unsigned long long lo = ~0ull, hi = 0ull;
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        if (t + k * SS_THREADS < n) {
+    for (int k = 0; k < RPT; ++k) {
+        if (t + k * THREADS < n) {
             const unsigned long long K = rec_key60(rec[k]);
             lo = K < lo ? K : lo;
             hi = K > hi ? K : hi;
@@ -901,25 +910,25 @@ __device__ __forceinline__ void sort_segment(
     __syncthreads();                      // also: boff / coarse zeroed
     lo = red_lo[0]; hi = red_hi[0];
 #pragma unroll
-    for (int w = 1; w < SS_WAVES; ++w) {
+    for (int w = 1; w < WAVES; ++w) {
         lo = red_lo[w] < lo ? red_lo[w] : lo;
         hi = red_hi[w] > hi ? red_hi[w] : hi;
     }
     if (SC_DIAG_BIT(dbg, 4)) return;      // diagnostic: price the load + min / max alone (nothing is emitted)
-    const double s1 = (double)SS_NC / ((double)(hi - lo) + 1.0);
+    const double s1 = (double)NC / ((double)(hi - lo) + 1.0);
     // key -> (coarse bin, position inside the bin in [0, 1]); monotone in the key
     auto level1 = [&](unsigned long long K, float& frac) -> int {
         const double p = (double)(K - lo) * s1;
         int c = (int)p;
-        c = c < SS_NC - 1 ? c : SS_NC - 1;
+        c = c < NC - 1 ? c : NC - 1;
         frac = (float)(p - (double)c);    // p - c is exact; (float) rounds monotonically
         return c;
     };
     // (the kernel needs <= 80 VGPRs for three workgroups per CU: the coarse bin is recomputed in the second
     //  counting pass, the fine bucket is kept from there for the scatter)
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        if (t + k * SS_THREADS < n) {
+    for (int k = 0; k < RPT; ++k) {
+        if (t + k * THREADS < n) {
             float frac;
             atomicAdd(&coarse[level1(rec_key60(rec[k]), frac)], 1u);
         }
@@ -932,7 +941,7 @@ __device__ __forceinline__ void sort_segment(
         __syncthreads();
         unsigned run = incl - c;
 #pragma unroll
-        for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
+        for (int w = 0; w < WAVES; ++w) if (w < wave) run += red_sum[w];
         coarse[t] = c | (run << 16);
     }
     __syncthreads();
@@ -945,11 +954,11 @@ __device__ __forceinline__ void sort_segment(
         f = f < cnt - 1 ? f : cnt - 1;
         return (int)(cs >> 16) + (f > 0 ? f : 0);
     };
-    int fj[SS_RPT];                            // the fine bucket of each of this thread's records (kept for the scatter)
+    int fj[RPT];                            // the fine bucket of each of this thread's records (kept for the scatter)
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
+    for (int k = 0; k < RPT; ++k) {
         fj[k] = 0;
-        if (t + k * SS_THREADS < n) {
+        if (t + k * THREADS < n) {
             fj[k] = fine_of(rec_key60(rec[k]));
             atomicAdd(&boff[fj[k]], 1u);
         }
@@ -957,7 +966,7 @@ __device__ __forceinline__ void sort_segment(
     __syncthreads();
     {   // exclusive scan of the n fine counters: thread t owns `per` consecutive ones (per is ODD: the
         // lanes' strides then hit 32 distinct banks instead of two)
-        const int per = ((n + SS_THREADS - 1) / SS_THREADS) | 1;
+        const int per = ((n + THREADS - 1) / THREADS) | 1;
         const int beg = min(t * per, n), end = min(beg + per, n);
         unsigned sum = 0;
         for (int i = beg; i < end; ++i) sum += boff[i];
@@ -967,7 +976,7 @@ __device__ __forceinline__ void sort_segment(
         __syncthreads();
         unsigned run = incl - sum;
 #pragma unroll
-        for (int w = 0; w < SS_WAVES; ++w) if (w < wave) run += red_sum[w];
+        for (int w = 0; w < WAVES; ++w) if (w < wave) run += red_sum[w];
         for (int i = beg; i < end; ++i) {      // counts -> bucket starts (used as running cursors)
             const unsigned c = boff[i];
             boff[i] = run;
@@ -978,8 +987,8 @@ __device__ __forceinline__ void sort_segment(
     if (SC_DIAG_BIT(dbg, 32)) return;     // diagnostic: ... and the fine counting pass + scan
     // scatter: after this pass boff[j] is the END of fine bucket j (== start of j + 1)
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        if (t + k * SS_THREADS < n) {
+    for (int k = 0; k < RPT; ++k) {
+        if (t + k * THREADS < n) {
             const uint2 r = rec[k];
             const int f = fj[k];
             const unsigned slot = atomicAdd(&boff[f], 1u);
@@ -995,16 +1004,16 @@ __device__ __forceinline__ void sort_segment(
     // key: ~40 VALU ops of double-precision mapping per record); all of a thread's bucket ids are read before
     // any rank is written, because order[] is also the output.  (One thread per BUCKET ranking its keys in
     // registers was measured too: 35 us instead of 22 for this phase -- divergence.)
-    unsigned short bj[SS_RPT];
+    unsigned short bj[RPT];
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        const int p = t + k * SS_THREADS;
+    for (int k = 0; k < RPT; ++k) {
+        const int p = t + k * THREADS;
         bj[k] = p < n ? order[p] : (unsigned short)0;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < SS_RPT; ++k) {
-        const int p = t + k * SS_THREADS;
+    for (int k = 0; k < RPT; ++k) {
+        const int p = t + k * THREADS;
         if (p >= n) break;
         const unsigned long long kk = B[p] & KEY_MASK;
         const int j = bj[k];
@@ -1014,7 +1023,7 @@ __device__ __forceinline__ void sort_segment(
         order[r] = (unsigned short)p;
     }
     __syncthreads();
-    emit_tiles<SS_THREADS>(B, order, n, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tb, table, isect_ids,
+    emit_tiles<THREADS>(B, order, n, sb, g, offsets, n_tbuckets, n_isects, tile_bits, tb, table, isect_ids,
                            flatten_ids, totals SC_DIAG_ARG(dbg));
     if (totals_out) {
         __syncthreads();
@@ -1066,7 +1075,8 @@ __device__ __forceinline__ void sort_heavy_segment(
 // One launch sorts everything: blocks [0, seg_bound) take the segments big_split_kernel produced (none in the
 // common case: those blocks return at once), blocks [seg_bound, seg_bound + n_sbuckets) the super-tiles whose
 // bucket fits the LDS capacity.
-__global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
+template <int THREADS, int RPT>
+__global__ __launch_bounds__(THREADS, 6) void super_sort_kernel(
     const uint2* __restrict__ records, uint2* __restrict__ records_rw, const uint2* __restrict__ temp,
     const Segment* __restrict__ segs, const unsigned* __restrict__ n_segs, int seg_bound,
     const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
     // (rendering._bin_launch_ran): a launch either runs in full or not at all
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     __shared__ int tb_s[4];
-    if ((int)blockIdx.x < seg_bound) {
+    if (THREADS == SS_THREADS && (int)blockIdx.x < seg_bound) {      // (the small form is launched without segments)
         if (blockIdx.x >= *n_segs) return;
         const Segment* sg = segs + blockIdx.x;
         if (threadIdx.x < 4) tb_s[threadIdx.x] = sg->tb[threadIdx.x];
@@ -1088,8 +1098,8 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
             sort_heavy_segment(temp + start, records_rw + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets,
                                meta[0], tile_bits, smem, isect_ids, flatten_ids);
         else
-            sort_segment(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem,
-                         isect_ids, flatten_ids, nullptr SC_DIAG_ARG(dbg));
+            sort_segment<SS_THREADS, SS_RPT>(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem,
+                                             isect_ids, flatten_ids, nullptr SC_DIAG_ARG(dbg));
         return;
     }
     const int sb = (int)blockIdx.x - seg_bound;
@@ -1099,8 +1109,8 @@ __global__ __launch_bounds__(SS_THREADS, 6) void super_sort_kernel(
     if (n <= 0 || n > cap) return;          // n > cap: big_split_kernel has cut this bucket into segments
     if (threadIdx.x < 4) tb_s[threadIdx.x] = 0;
     __syncthreads();
-    sort_segment(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
-                 flatten_ids, nullptr SC_DIAG_ARG(dbg));
+    sort_segment<THREADS, RPT>(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
+                               flatten_ids, nullptr SC_DIAG_ARG(dbg));
 }
 
 // ---- isect_ids on demand ------------------------------------------------------------------------------------
@@ -1385,7 +1395,7 @@ static hipError_t bin_attrs_once() {
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS, 64>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel<SS_THREADS, SS_RPT>, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
     done[dev] = true;
     return hipSuccess;
 }
@@ -1603,10 +1613,17 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
                            n_segs, seg_bound, soffsets, L.nsb, meta_dev, capacity, rec_capacity, super_capacity, cap SC_DIAG_ARG(g_sc_debug[3]));
         SC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(super_sort_kernel, dim3((unsigned)(seg_bound + L.nsb)), dim3(SS_THREADS), sort_lds_bytes(cap), s,
-                       (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
-                       (const unsigned*)n_segs, seg_bound, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
-                       capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
+    if (!big && cap <= SS_SMALL_CAP)
+        hipLaunchKernelGGL((super_sort_kernel<SS_SMALL_THREADS, SS_SMALL_RPT>), dim3((unsigned)L.nsb), dim3(SS_SMALL_THREADS),
+                           sort_lds_bytes(cap, SS_SMALL_THREADS), s,
+                           (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
+                           (const unsigned*)n_segs, 0, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
+                           capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
+    else
+        hipLaunchKernelGGL((super_sort_kernel<SS_THREADS, SS_RPT>), dim3((unsigned)(seg_bound + L.nsb)), dim3(SS_THREADS), sort_lds_bytes(cap), s,
+                           (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
+                           (const unsigned*)n_segs, seg_bound, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
+                           capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

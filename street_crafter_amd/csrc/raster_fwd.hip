@@ -42,7 +42,6 @@ __global__ void raster_fwd_ref_kernel(
     int* id_s = reinterpret_cast<int*>(smem);                              // [B]
     float4* xyoa_s = reinterpret_cast<float4*>(smem + (size_t)B * 16);     // [B] mx,my,opac,conic.a
     float2* bc_s = reinterpret_cast<float2*>(smem + (size_t)B * 32);       // [B] conic.b, conic.c
-    __shared__ int done_cnt_s;
 
     const int cam = blockIdx.z;
     const int tile_id = blockIdx.y * tile_width + blockIdx.x;
@@ -116,7 +115,6 @@ __global__ void raster_fwd_ref_kernel(
             T = next_T;
         }
     }
-    (void)done_cnt_s;
     if (inside) {
         render_alphas[pix] = 1.0f - T;
 #pragma unroll
@@ -327,7 +325,7 @@ __device__ __forceinline__ void raster_item(
         SC_DIAG_DRAIN(prof);
         const unsigned long long pcw = SC_DIAG_CLOCK(prof);
         if (prof && b == 0) pc_first = pcw - pc_begin;
-        walked += 4 * SB;                 // a staged batch of 128 (gather + cull) weighs about 8 blend iterations
+        walked += 4 * SB;                 // a staged batch of 64 (gather + cull) weighs about 4 blend iterations
         // ---- cull + compact (wave-level, no workgroup barrier needed: the workgroup is this wave)
         int bsz = 0;
         __syncthreads();   // single-wave workgroup: orders the previous batch's LDS reads vs these writes
