@@ -253,9 +253,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
         raise NotImplementedError("packed=True is not supported (reference passes packed=False)")
     lib = _lib.load()
     view_cams = getattr(means2d, "_sc_viewmats", None)
-    means2d = _req(means2d.detach(), "means2d")
+    # (detach only what autograd tracks: a detach is ~2 us of host time, and small frames are bound by this wrapper)
+    means2d = _req(means2d.detach() if means2d.requires_grad else means2d, "means2d")
     radii = _req(radii, "radii", torch.int32)
-    depths = _req(depths.detach(), "depths")
+    depths = _req(depths.detach() if depths.requires_grad else depths, "depths")
     C, N = radii.shape
     assert means2d.shape == (C, N, 2), means2d.shape
     assert depths.shape == (C, N), depths.shape
@@ -518,7 +519,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             _BIN_PREDICTION.pop(old, None)
             _BIN_LAST_META.pop(old, None)
     hist.append((n_isects, n_records, max_super))
-    mi, mr, ms = (max(h[j] for h in hist) for j in range(3))
+    mi, mr, ms = map(max, zip(*hist))
     _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
     flatten_ids = fids[:n_isects]
     isect_ids = None
