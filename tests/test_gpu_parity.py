@@ -302,6 +302,34 @@ def test_isect_bin_oversized_super_tiles_are_split_not_abandoned(ops, shape):
     assert rendering._BIN_LAST_META[key][2] > 20000           # the bucketed route ran, with a 20k+ bucket
 
 
+@pytest.mark.parametrize("n_in_bucket", [120, 1000, 1024, 1030, 1290, 3500])
+def test_isect_bin_small_and_large_bucket_sorts_agree_with_the_oracle(ops, n_in_bucket):
+    """Frames whose largest super-tile bucket fits 1024 records are sorted by the 128-thread form of the bucket sort
+    (super_sort_kernel<128, 8>), larger ones by the 512-thread form: both sides of the switch (the capacity is the
+    largest bucket rounded up to 256: 1024 / 1280), depth ties included, first with exact and then with predicted
+    sizes (predicted = 12.5 % over: 1000 records then provision 1280, the other form again)."""
+    from street_crafter_amd import rendering
+    rng = np.random.default_rng(n_in_bucket)
+    N = n_in_bucket + 600
+    m2 = rng.uniform(40, 56, size=(1, N, 2)).astype(np.float32)           # one super-tile (tiles 2..3) holds the bucket ...
+    m2[0, n_in_bucket:] = rng.uniform(64, 192, size=(600, 2))             # ... the rest is spread over its neighbours
+    r = np.ones((1, N), dtype=np.int32)
+    r[0, n_in_bucket:] = rng.integers(1, 9, size=600)
+    d = rng.uniform(1.0, 50.0, size=(1, N)).astype(np.float32)
+    d[0, : n_in_bucket // 3] = 12.5                                       # a third of the bucket ties on depth
+    e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 12, 12)
+    key = (torch.cuda.current_device(), 1, N, 16, 12, 12)
+    rendering._BIN_LAST_META.pop(key, None)
+    rendering._BIN_PREDICTION.pop(key, None)
+    rendering._BIN_HISTORY.pop(key, None)
+    for _ in range(2):
+        tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 12, 12)
+        np.testing.assert_array_equal(_np(tpg), e_tpg)
+        np.testing.assert_array_equal(_np(ids), e_ids)
+        np.testing.assert_array_equal(_np(fids), e_f)
+    assert rendering._BIN_LAST_META[key][2] >= n_in_bucket                # the bucketed route ran, bucket as built
+
+
 def test_isect_bin_street_scene_matches_the_radix_route(ops):
     """The street-shaped scene (dense horizon band: hundreds of oversized super-tiles; sky splats hundreds of
     pixels wide: rectangles of hundreds of tiles) through both routes at full resolution: bit-identical."""
