@@ -15,6 +15,9 @@ import gsplat.rendering as R  # noqa: E402
 from street_crafter_amd import _lib, rendering  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene  # noqa: E402
 
+if os.environ.get("FUZZ_LIB"):       # FUZZ_LIB=tag: check an experiment build (SC_DIAG_TAG=tag ... build --diag) instead of the shipped library
+    _lib.use_diagnostic_build("" if os.environ["FUZZ_LIB"] == "diag" else os.environ["FUZZ_LIB"])
+    _lib.set_fast_binding(False)     # (the compiled binding layer is linked to the shipped library)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
