@@ -119,10 +119,16 @@ class FrameGatherer:
     `force_collective=True`, which sends a world of one through the very same staging ring, stream events and
     async `dist.gather` calls as a world of eight (needs an initialised process group): the only way to execute
     the RCCL transport path on a one-GPU box (tests/test_gpu_parity.py::test_rccl_gather_ring_at_world_one,
-    `bench.py --force-gather`)."""
+    `bench.py --force-gather`).
+
+    `reserve_rounds` = R > 0: the caller knows how many rounds it will render (a video of R frames per rank): the
+    memory the delivered frames live in -- uint8 [R,H,W,3] at one rank, [R/batch, world, batch, H,W,3] on dst -- is
+    allocated ONCE here instead of one 7.4 MB tensor per frame (one rank) or `world` 59 MB tensors per collective
+    (dst) in the render loop: a first pass over fresh memory is a hipMalloc per allocation, ~0.1 ms each on the
+    host.  Rounds beyond R fall back to per-frame allocation."""
 
     def __init__(self, frame_shape: Sequence[int], device, dst: int = 0, group=None, batch: int = 8,
-                 ring: int = 3, keep: bool = True, force_collective: bool = False):
+                 ring: int = 3, keep: bool = True, force_collective: bool = False, reserve_rounds: int = 0):
         self.dst, self.group = dst, group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -136,6 +142,16 @@ class FrameGatherer:
         self._local = self.world == 1 and not force_collective
         self._staging = [] if self._local else [
             torch.empty((self.batch, *self.shape), dtype=torch.uint8, device=self.device) for _ in range(self.ring)]
+        self._reserved = max(0, int(reserve_rounds))
+        self._block = None                 # one rank: the delivered frames' storage, uint8 [R, *shape]
+        self._recv_block = None            # dst of a real gather: uint8 [ceil(R / batch), world, batch, *shape]
+        if self._reserved and keep:
+            if self._local:
+                self._block = torch.empty((self._reserved, *self.shape), dtype=torch.uint8, device=self.device)
+            elif self.rank == self.dst:
+                nb = (self._reserved + self.batch - 1) // self.batch
+                self._recv_block = torch.empty((nb, self.world, self.batch, *self.shape), dtype=torch.uint8,
+                                               device=self.device)
         self._single: Dict[int, torch.Tensor] = {}
         self._busy: List[Optional[object]] = [None] * self.ring    # outstanding work per ring entry
         self._events: Dict[int, object] = {}                      # round -> event on its stream (HIP only)
@@ -149,7 +165,11 @@ class FrameGatherer:
         if self._local:
             t = self._single.get(int(round_index))
             if t is None:
-                t = self._single[int(round_index)] = torch.empty(self.shape, dtype=torch.uint8, device=self.device)
+                if self._block is not None and 0 <= int(round_index) < self._reserved:
+                    t = self._block[int(round_index)]
+                else:
+                    t = torch.empty(self.shape, dtype=torch.uint8, device=self.device)
+                self._single[int(round_index)] = t
             return t
         b, j = divmod(int(round_index), self.batch)
         e = b % self.ring
@@ -202,7 +222,10 @@ class FrameGatherer:
                     cur.wait_event(ev)
         recv = None
         if self.rank == self.dst:
-            recv = [torch.empty_like(send) for _ in range(self.world)]
+            if self._recv_block is not None and b < self._recv_block.shape[0]:
+                recv = [self._recv_block[b, k, :n_rounds] for k in range(self.world)]
+            else:
+                recv = [torch.empty_like(send) for _ in range(self.world)]
         work = dist.gather(send, gather_list=recv, dst=self.dst, group=self.group, async_op=True)
         self._busy[e] = work
         self._pending.append((work, b, n_rounds, recv))
@@ -270,7 +293,7 @@ def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst
             if g is None:                 # the first frame tells the frame shape / device
                 first = render_frame(f)
                 g = FrameGatherer(first.shape, first.device, dst, group, batch=min(batch, len(mine)), ring=ring,
-                                  force_collective=force_collective)
+                                  force_collective=force_collective, reserve_rounds=len(mine))
                 render_sharded.last_stats = g.stats          # (for tests / the bench line)
                 if frames_in_flight > 1 and first.is_cuda:
                     streams = [torch.cuda.Stream(device=first.device) for _ in range(int(frames_in_flight))]

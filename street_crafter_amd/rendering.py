@@ -12,12 +12,14 @@ from __future__ import annotations
 import collections
 import math
 import threading
+import weakref
 from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
 
 from . import _lib
+from .lazy import LazyTensor as _LazyTensor
 
 __all__ = ["fully_fused_projection", "isect_tiles", "isect_offset_encode", "spherical_harmonics",
            "rasterize_to_pixels", "rasterization"]
@@ -267,7 +269,7 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     mode = _ISECT_MODE["mode"] if sort else "radix"
     if mode == "bin":
         res = _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                               None, None, st, viewmats=view_cams)
+                               None, None, st, viewmats=view_cams, defer=True)
         if res is not None:
             return res[:3]
     tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
@@ -384,6 +386,54 @@ _PINNED_META = threading.local()   # .slots: device index -> [pinned int64[8] th
                                    # numpy view, seq] of THIS host thread
 
 
+_DEFER_ISECT = {"on": True}
+
+
+def set_deferred_isect(enabled: bool) -> bool:
+    """isect_tiles' host wait for the frame's intersection count: True (default) = deferred to the first observation of
+    `flatten_ids` / `isect_ids` (normally inside rasterize_to_pixels, by when the count has long arrived: lazy.py), False =
+    inside isect_tiles as before.  Applies when a prediction of the buffer sizes exists (from the second call of a frame
+    shape on).  Results are identical either way.  Returns the previous setting."""
+    prev, _DEFER_ISECT["on"] = _DEFER_ISECT["on"], bool(enabled)
+    return prev
+
+
+class _PendingIsect:
+    """The part of one isect_tiles call that needs the frame's counts on the host: wait, check of the predicted launch
+    (exact relaunch when it was too small), bookkeeping for the next prediction, and the final length of the two id
+    tensors.  Shared by the `flatten_ids` and `isect_ids` LazyTensors of the call (each holds it; it holds them weakly)
+    and by the pinned meta slot of the host thread (weakly): the next isect_tiles call of the thread settles it first,
+    because the slot's words are overwritten by every count phase."""
+    __slots__ = ("settle", "flat_ref", "ids_ref", "done", "lock", "flat_plain", "error", "__weakref__")
+
+    def __init__(self, settle):
+        self.settle, self.flat_ref, self.ids_ref = settle, None, None
+        self.done, self.lock, self.flat_plain, self.error = False, threading.Lock(), None, None
+
+    def resolve(self, _tensor=None):
+        with self.lock:
+            if self.done:
+                return
+            if self.error is not None:         # (e.g. more than 2^31 - 1 intersections: every observation says so)
+                raise self.error
+            settle, self.settle = self.settle, None
+            try:
+                fids, ids_buf, after = settle()
+            except BaseException as e:
+                self.error = e
+                raise
+            self.flat_plain = fids
+            with torch._C.DisableTorchFunctionSubclass():
+                for ref, src in ((self.flat_ref, fids), (self.ids_ref, ids_buf)):
+                    t = ref() if ref is not None else None
+                    if t is not None and src is not None:
+                        t.set_(src)
+                        t.__dict__["_sc_resolve"] = None      # (settled through the other tensor / the next call)
+            self.done = True
+            if after is not None:
+                after()
+
+
 def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
     """True iff a bucket scatter + sort launched with `capacities` = (capacity, rec_capacity, super_capacity)
     passed the device-side size check, i.e. ran in full.  Must mirror the kernels' test
@@ -393,7 +443,7 @@ def _bin_launch_ran(capacities, n_isects, n_records, max_super) -> bool:
 
 
 def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height,
-                     tiles_per_gauss, total_dev, st, want_ids=True, viewmats=None):
+                     tiles_per_gauss, total_dev, st, want_ids=True, viewmats=None, defer=False):
     """-> (tiles_per_gauss, isect_ids | None, flatten_ids, isect_offsets), or None when the shape is outside
     the tile-bucketed path's limits.  want_ids=False skips the 8 B x I key array altogether (the fused
     rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
@@ -412,7 +462,15 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     slot = slots.get(dev.index)
     if slot is None:
         host = torch.zeros(8, dtype=torch.int64, pin_memory=True)
-        slot = slots[dev.index] = [host, host.numpy(), 0, host.data_ptr()]
+        slot = slots[dev.index] = [host, host.numpy(), 0, host.data_ptr(), None]
+    if len(slot) > 4 and slot[4] is not None:      # an earlier call of this thread whose counts nobody has looked at yet
+        prev_pending = slot[4]()
+        slot[4] = None
+        if prev_pending is not None:
+            try:
+                prev_pending.resolve()
+            except Exception:      # noqa: BLE001  (kept on the pending call: its own tensors raise it when looked at)
+                pass
     meta_np, meta_ptr = slot[1], slot[3]
     slot[2] += 1
     seq = slot[2]
@@ -486,60 +544,119 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             rc = None
         elif rc != 0:
             _lib.check(rc, "sc_isect_bin_sort")
-    n_isects, _, n_records, max_super = read_meta()     # the one host wait of a frame; GPU already has work
-    _check_isect_count(n_isects, C, N, tile_width, tile_height)
-    # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
-    # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
-    _BIN_STATS["calls"] += 1
-    if rc is not None and _bin_launch_ran(pred, n_isects, n_records, max_super):
-        _BIN_STATS["speculative_ok"] += 1
-    elif rc is not None:
-        _BIN_STATS["exact_relaunch"] += 1
-    if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):
-        if rc is not None:     # a predicted launch was enqueued and (by the device's own check) did nothing:
-            # belt and braces, the cursors are re-zeroed before the exact-size launch all the same
-            _lib.check(lib.sc_isect_bin_reset_cursors(_p(ws0), C * N, C, int(tile_width), int(tile_height), st),
-                       "sc_isect_bin_reset_cursors")
-        rc, ids, fids = launch(n_isects, n_records, max_super)
-        if rc == -3:
-            return None
-        _lib.check(rc, "sc_isect_bin_sort")
-    _BIN_LAST_META[key] = (n_isects, n_records, max_super)
-    # next call: 12.5 % head-room over the largest of the last 8 calls of this shape (a rig's cameras are rendered
-    # in turn and see different amounts of the scene: sized by the previous call alone, every switch to a fuller view
-    # missed the prediction and paid the host round trip + a second launch)
-    hist = _BIN_HISTORY.get(key)
-    if hist is None:
-        hist = _BIN_HISTORY[key] = collections.deque(maxlen=_BIN_HISTORY_LEN)
-        while len(_BIN_HISTORY) > _BIN_KEYS_MAX:
-            # one key per distinct (device, C, N, tile grid): densification changes N every 100 training iterations
-            # (train.py:292-310), so all three per-shape tables are pruned together, oldest shape first
-            old = next(iter(_BIN_HISTORY))
-            _BIN_HISTORY.pop(old)
-            _BIN_PREDICTION.pop(old, None)
-            _BIN_LAST_META.pop(old, None)
-    hist.append((n_isects, n_records, max_super))
-    mi, mr, ms = map(max, zip(*hist))
-    _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
+
+    def settle(rc=rc, ids=ids, fids=fids):
+        """Everything that needs the frame's counts on the host.  -> (n_isects, ids, fids), or None when the frame is
+        outside the tile-bucketed path's limits (the caller takes the reference-shaped route)."""
+        n_isects, _, n_records, max_super = read_meta()     # the one host wait of a frame; GPU already has work
+        _check_isect_count(n_isects, C, N, tile_width, tile_height)
+        # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
+        # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
+        _BIN_STATS["calls"] += 1
+        if rc is not None and _bin_launch_ran(pred, n_isects, n_records, max_super):
+            _BIN_STATS["speculative_ok"] += 1
+        elif rc is not None:
+            _BIN_STATS["exact_relaunch"] += 1
+        if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):
+            if rc is not None:     # a predicted launch was enqueued and (by the device's own check) did nothing:
+                # belt and braces, the cursors are re-zeroed before the exact-size launch all the same
+                _lib.check(lib.sc_isect_bin_reset_cursors(_p(ws0), C * N, C, int(tile_width), int(tile_height), st),
+                           "sc_isect_bin_reset_cursors")
+            if _stream(means2d) != st:      # (settled late, under another current stream: allocate where the kernels run)
+                with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
+                    rc, ids, fids = launch(n_isects, n_records, max_super)
+            else:
+                rc, ids, fids = launch(n_isects, n_records, max_super)
+            if rc == -3:
+                return None
+            _lib.check(rc, "sc_isect_bin_sort")
+        _BIN_LAST_META[key] = (n_isects, n_records, max_super)
+        # next call: 12.5 % head-room over the largest of the last 8 calls of this shape (a rig's cameras are rendered
+        # in turn and see different amounts of the scene: sized by the previous call alone, every switch to a fuller view
+        # missed the prediction and paid the host round trip + a second launch)
+        hist = _BIN_HISTORY.get(key)
+        if hist is None:
+            hist = _BIN_HISTORY[key] = collections.deque(maxlen=_BIN_HISTORY_LEN)
+            while len(_BIN_HISTORY) > _BIN_KEYS_MAX:
+                # one key per distinct (device, C, N, tile grid): densification changes N every 100 training iterations
+                # (train.py:292-310), so all three per-shape tables are pruned together, oldest shape first
+                old = next(iter(_BIN_HISTORY))
+                _BIN_HISTORY.pop(old)
+                _BIN_PREDICTION.pop(old, None)
+                _BIN_LAST_META.pop(old, None)
+        hist.append((n_isects, n_records, max_super))
+        mi, mr, ms = map(max, zip(*hist))
+        _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
+        return n_isects, ids, fids
+
+    def make_fill(get_flat, n_isects_of):
+        # isect_ids: allocated now, written on first use (one kernel, from flatten_ids / offsets / depths)
+        def fill(buf, off=offsets, dep=depths, producer=st):
+            fl, n_isects = get_flat(), n_isects_of()
+            cur = _stream(buf)
+            if cur != producer:            # filled from another stream than the one that sorted: order them
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.ExternalStream(producer, device=dev))
+                torch.cuda.current_stream(dev).wait_event(ev)
+            _lib.check(lib.sc_isect_ids_rebuild(fl.data_ptr(), off.data_ptr(), dep.data_ptr(), C, N,
+                                                int(tile_width), int(tile_height), n_isects, buf.data_ptr(),
+                                                cur), "sc_isect_ids_rebuild")
+        return fill
+
+    if defer and rc == 0 and want_ids and not eager_ids and _DEFER_ISECT["on"]:
+        # The predicted scatter + sort are enqueued; the wait for the counts, the check of the prediction and the true
+        # length of the two id tensors are settled on their first observation (lazy.py) -- on the reference's path
+        # inside rasterize_to_pixels, three torch calls later, when the counts have arrived.
+        from .lazy import LazyTensor
+        state = {}
+
+        def after():
+            t = pending.ids_ref() if pending.ids_ref is not None else None
+            if t is not None:       # set_ has bumped the version the cached offsets were filed under
+                with torch._C.DisableTorchFunctionSubclass():
+                    t._sc_offsets = (offsets, C, int(tile_width), int(tile_height), t._version)
+
+        def settle_deferred():
+            res = settle()
+            if res is None:       # outside the bucketed path's limits after all: the reference-shaped route, now
+                prev = set_isect_mode("radix")
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
+                        _, ids2, fids2 = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height)
+                finally:
+                    set_isect_mode(prev)
+                state["n"] = fids2.numel()
+                pend_ids = pending.ids_ref() if pending.ids_ref is not None else None
+                if pend_ids is not None:
+                    pend_ids.__dict__["_sc_fill"] = None          # (the radix route has written the keys)
+                return fids2, ids2, after
+            n_isects, _, fids_ = res
+            state["n"] = n_isects
+            return fids_[:n_isects], torch.empty(n_isects, dtype=torch.int64, device=dev), after
+
+        pending = _PendingIsect(settle_deferred)
+        flatten_ids = LazyTensor(fids[:0], None, pending.resolve)
+        isect_ids = LazyTensor(torch.empty(0, dtype=torch.int64, device=dev),
+                               make_fill(lambda: pending.flat_plain, lambda: state["n"]), pending.resolve)
+        pending.flat_ref, pending.ids_ref = weakref.ref(flatten_ids), weakref.ref(isect_ids)
+        with torch._C.DisableTorchFunctionSubclass():
+            isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
+        slot[4] = weakref.ref(pending)
+        return tiles_per_gauss, isect_ids, flatten_ids, offsets
+
+    res = settle()
+    if res is None:
+        return None
+    n_isects, ids, fids = res
     flatten_ids = fids[:n_isects]
     isect_ids = None
     if want_ids:
         if eager_ids:
             isect_ids = ids[:n_isects]
         else:
-            # allocated now, written on first use (one kernel, from flatten_ids / offsets / depths)
-            def fill(buf, fl=flatten_ids, off=offsets, dep=depths, producer=st):
-                cur = _stream(buf)
-                if cur != producer:            # filled from another stream than the one that sorted: order them
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.ExternalStream(producer, device=dev))
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                _lib.check(lib.sc_isect_ids_rebuild(fl.data_ptr(), off.data_ptr(), dep.data_ptr(), C, N,
-                                                    int(tile_width), int(tile_height), n_isects, buf.data_ptr(),
-                                                    cur), "sc_isect_ids_rebuild")
-
             from .lazy import LazyTensor
-            isect_ids = LazyTensor(torch.empty(n_isects, dtype=torch.int64, device=dev), fill)
+            isect_ids = LazyTensor(torch.empty(n_isects, dtype=torch.int64, device=dev),
+                                   make_fill(lambda: flatten_ids, lambda: n_isects))
         # the bucket scan already IS isect_offset_encode's result: remember it on the tensor object so
         # the caller's next call (renderer.py:253) does not re-read the 8 B x I key array
         isect_ids._sc_offsets = (offsets, C, int(tile_width), int(tile_height), isect_ids._version)
@@ -762,6 +879,8 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
     colors = _req(colors, "colors")
     opacities = _req(opacities, "opacities")
     isect_offsets = _req(isect_offsets, "isect_offsets", torch.int32)
+    if type(flatten_ids) is _LazyTensor:      # isect_tiles' deferred list: the frame's counts are settled here (lazy.py)
+        flatten_ids = flatten_ids.plain()
     flatten_ids = _req(flatten_ids, "flatten_ids", torch.int32)
     C, N = opacities.shape
     D = colors.shape[-1]

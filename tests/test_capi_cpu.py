@@ -360,6 +360,52 @@ def test_lazy_tensor_copies_and_serialisation_are_plain_filled_tensors():
     assert type(d["isect_ids"]) is torch.Tensor and d["isect_ids"].tolist() == want and calls == [1]
 
 
+def test_lazy_tensor_with_a_deferred_shape():
+    """lazy.py, round 3: a LazyTensor whose LENGTH is settled on first observation (isect_tiles hands out flatten_ids /
+    isect_ids before the frame's intersection count has reached the host).  What does not depend on the length is
+    answered without resolving; shape, numel, len and every read resolve first (once), the same Python object then has
+    the true length; copies and serialisation hand out plain tensors of the true length."""
+    import copy
+    import pickle
+    import torch
+    from street_crafter_amd.lazy import LazyTensor
+    cap = torch.zeros(10, dtype=torch.int32)
+    log = []
+
+    def make(fill=True):
+        def resolve(t):
+            log.append("resolve")
+            t.set_(cap.untyped_storage(), 0, (4,), (1,))
+
+        def fill_(t):
+            log.append("fill")
+            t.copy_(torch.arange(4, dtype=torch.int32) * 5)
+        return LazyTensor(cap[:0], fill_ if fill else None, resolve)
+
+    z = make()
+    assert isinstance(z, torch.Tensor) and not z.is_resolved and not z.is_materialized
+    assert (z.dtype, str(z.device), z.ndim, z.dim(), z.is_cuda, z.requires_grad, z.is_contiguous()) == \
+           (torch.int32, "cpu", 1, 1, False, False, True)
+    z._sc_note = "attributes ride along"
+    assert log == [] and z._version == 0
+    assert z.shape == (4,) and log == ["resolve"] and z.is_resolved and not z.is_materialized       # shape: resolve only
+    assert z.numel() == 4 and len(z) == 4 and log == ["resolve"]
+    assert z.tolist() == [0, 5, 10, 15] and log == ["resolve", "fill"] and z.is_materialized and z._sc_note
+    for observe in (lambda t: t.shape, lambda t: t.numel(), lambda t: len(t), lambda t: t.size(0), lambda t: t.cpu(),
+                    lambda t: t.tolist(), lambda t: t.data_ptr(), lambda t: repr(t), lambda t: t + 1, lambda t: t[1:3],
+                    lambda t: torch.cat([t, t]), lambda t: t.contiguous(), lambda t: t.plain(), lambda t: t.materialize()):
+        log.clear()
+        t = make()
+        observe(t)
+        assert log and log[0] == "resolve" and log.count("resolve") == 1, observe
+        assert t.shape == (4,) and t.tolist() == [0, 5, 10, 15] and log.count("fill") == 1
+    for fn in (copy.deepcopy, lambda t: pickle.loads(pickle.dumps(t)), lambda t: t.clone()):
+        out = fn(make())
+        assert type(out) is torch.Tensor and out.tolist() == [0, 5, 10, 15]
+    t = make(fill=False)                  # no contents to produce (flatten_ids: the sort has written them)
+    assert type(t.plain()) is torch.Tensor and t.plain().shape == (4,) and t.plain().data_ptr() == cap.data_ptr()
+
+
 def test_compiled_binding_layer_loads_and_refuses_cpu_tensors(lib):
     """csrc/binding.cpp -> lib/_sc_fast.so: the default host path.  It must be the same build as the library (version
     string), export one entry per hot operator call, and refuse tensors that are not on a HIP device before anything

@@ -146,6 +146,91 @@ def test_isect_ids_are_lazy_on_the_bucketed_route_and_exact_when_read(ops, golde
         rendering.set_lazy_isect_ids(prev)
 
 
+def test_isect_tiles_defers_its_host_wait_to_the_first_observation(ops):
+    """Round 3 (street_crafter_amd/lazy.py, rendering._PendingIsect): from the second call of a frame shape on,
+    isect_tiles enqueues scatter + sort with predicted sizes and returns WITHOUT waiting for the frame's counts;
+    flatten_ids / isect_ids settle their length on first observation (rasterize_to_pixels on the reference's path).
+    Same tensors as the eager form, bit for bit: in the good case, after a mis-prediction (exact relaunch inside the
+    settle), when the outputs are never looked at, and when two calls follow each other unobserved."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.lazy import LazyTensor
+    from street_crafter_amd.scenes import make_camera, make_scene
+    sc = make_scene(30_000, seed=77).to(DEV)
+    W, H, tw, th = 640, 416, 40, 26
+    key = (torch.cuda.current_device(), 1, sc.n, 16, tw, th)
+
+    def project(yaw):
+        cam = make_camera(W, H, 680.0, 680.0, yaw=yaw).to(DEV)
+        with torch.no_grad():
+            r, m2, d, con, comp = ops.fully_fused_projection(sc.means, None, sc.quats, sc.scales, cam.viewmat[None], cam.K[None],
+                                                              W, H, near_plane=0.001, far_plane=1000.0, calc_compensations=True)
+        return r, m2, d, con, comp
+
+    def eager(a):
+        prev = rendering.set_deferred_isect(False)
+        try:
+            tpg, ids, fids = ops.isect_tiles(a[1], a[0], a[2], 16, tw, th, n_cameras=1)
+            return tpg, ids.clone(), fids.clone(), ops.isect_offset_encode(ids, 1, tw, th).clone()
+        finally:
+            rendering.set_deferred_isect(prev)
+
+    for d_ in (rendering._BIN_PREDICTION, rendering._BIN_HISTORY, rendering._BIN_LAST_META):
+        d_.pop(key, None)
+    a0, a1 = project(0.0), project(0.3)
+    e0, e1 = eager(a0), eager(a1)                                        # (also teaches the prediction)
+    assert e0[2].numel() != e1[2].numel()
+    # 1. deferred, good prediction: nothing is settled by the call, by metadata that does not need the length, or by
+    #    isect_offset_encode; shape / contents settle it
+    stats = dict(rendering._BIN_STATS)
+    tpg, ids, fids = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
+    assert type(fids) is LazyTensor and type(ids) is LazyTensor and not fids.is_resolved and not ids.is_resolved
+    assert fids.dtype == torch.int32 and ids.dtype == torch.int64 and fids.is_cuda and fids.ndim == 1
+    off = ops.isect_offset_encode(ids, 1, tw, th)
+    assert not fids.is_resolved and not ids.is_resolved and rendering._BIN_STATS["calls"] == stats["calls"]
+    assert torch.equal(off, e0[3]) and torch.equal(tpg, e0[0])
+    assert fids.shape == e0[2].shape and fids.is_resolved and ids.is_resolved and not ids.is_materialized
+    assert rendering._BIN_STATS["calls"] == stats["calls"] + 1 and rendering._BIN_STATS["speculative_ok"] == stats["speculative_ok"] + 1
+    assert ids.shape == e0[1].shape and torch.equal(fids, e0[2]) and torch.equal(ids, e0[1]) and ids.is_materialized
+    assert torch.equal(ops.isect_offset_encode(ids, 1, tw, th), e0[3])
+    # 2. the rasterizer settles it: image equal to the eager call's
+    def image(a, off, fids):
+        cols = torch.rand(1, sc.n, 3, device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+        return ops.rasterize_to_pixels(a[1], a[3], cols, sc.opacities[None, :, 0] * a[4], W, H, 16, off, fids)
+    tpg, ids, fids = ops.isect_tiles(a1[1], a1[0], a1[2], 16, tw, th, n_cameras=1)
+    off = ops.isect_offset_encode(ids, 1, tw, th)
+    assert not fids.is_resolved
+    img = image(a1, off, fids)
+    assert fids.is_resolved and torch.equal(fids, e1[2])
+    ref = image(a1, e1[3], e1[2])
+    assert torch.equal(img[0], ref[0]) and torch.equal(img[1], ref[1])
+    # 3. a prediction that is too small: the settle relaunches with exact sizes; one that is generous: no relaunch
+    for pred, relaunch in (((16, 16, 16), 1), ((1 << 26, 1 << 26, 3000), 0)):
+        rendering._BIN_PREDICTION[key] = pred
+        stats = dict(rendering._BIN_STATS)
+        tpg, ids, fids = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
+        assert not fids.is_resolved
+        assert torch.equal(fids, e0[2]) and torch.equal(ids, e0[1]) and torch.equal(tpg, e0[0])
+        assert rendering._BIN_STATS["exact_relaunch"] == stats["exact_relaunch"] + relaunch
+    # 4. two calls in a row, the first never looked at: the second call settles it (the pinned slot is shared), and the
+    #    first's tensors are still right afterwards; outputs dropped unobserved leave nothing behind
+    t0 = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
+    assert not t0[2].is_resolved
+    t1 = ops.isect_tiles(a1[1], a1[0], a1[2], 16, tw, th, n_cameras=1)
+    assert t0[2].is_resolved and not t1[2].is_resolved
+    assert torch.equal(t1[2], e1[2]) and torch.equal(t0[2], e0[2]) and torch.equal(t0[1], e0[1]) and torch.equal(t1[1], e1[1])
+    ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)          # dropped at once
+    t2 = ops.isect_tiles(a1[1], a1[0], a1[2], 16, tw, th, n_cameras=1)
+    assert torch.equal(t2[2], e1[2])
+    # 5. only isect_ids kept and read
+    ids_only = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)[1]
+    assert torch.equal(ids_only, e0[1])
+    # 6. settled from another stream than the producing one
+    t3 = ops.isect_tiles(a1[1], a1[0], a1[2], 16, tw, th, n_cameras=1)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        host_f, host_i = t3[2].cpu(), t3[1].cpu()
+    assert torch.equal(host_f, e1[2].cpu()) and torch.equal(host_i, e1[1].cpu())
+
+
 def test_isect_unsorted_and_empty(ops, golden_dir):
     g = _load(golden_dir, "pipeline_small.npz")
     m2, r, d = _t(g["means2d"])[None], _t(g["radii"], torch.int32)[None], _t(g["depths"])[None]

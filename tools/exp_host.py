@@ -16,6 +16,9 @@ from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_scene  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+if os.environ.get("SC_DEFER") == "0":      # A/B: isect_tiles waits for the frame's counts itself (round 2's form)
+    from street_crafter_amd import rendering as _r
+    _r.set_deferred_isect(False)
 dev = "cuda"
 W, H = 1920, 1280
 cams = [bench.frame_camera(s, W, H).to(dev) for s in range(frames + 10)]
