@@ -145,6 +145,10 @@ int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* 
  * into.  Scheduling only: any slot renders the same image. */
 int sc_view_slots(void);
 int sc_view_registry_words(void);
+/* Records of the largest super-tile bucket one workgroup of sc_isect_bin_sort sorts in LDS (3584).  A caller that
+ * predicts `super_capacity` with head-room should not let the head-room alone cross this value: above it every call
+ * also launches the split kernel and the segment workgroups, whether or not a bucket is that large. */
+int sc_isect_bin_bucket_capacity(void);
 int sc_isect_bin_sort(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                       int tile_size, int tile_width, int tile_height,
                       const int32_t* isect_offsets, const int64_t* meta_dev,

@@ -65,6 +65,7 @@ SIGNATURES = {
                                      c_i32p, c_stream]),
     "sc_view_slots": (C.c_int, []),
     "sc_view_registry_words": (C.c_int, []),
+    "sc_isect_bin_bucket_capacity": (C.c_int, []),
     "sc_isect_bin_sort": (C.c_int, [c_f32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_i32p, c_i64p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i64p,
                                     c_i32p, C.c_void_p, C.c_size_t, c_stream]),

@@ -1422,6 +1422,7 @@ extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width
 
 extern "C" int sc_view_slots(void) { return SC_VIEW_SLOTS; }
 extern "C" int sc_view_registry_words(void) { return SC_VIEW_REGISTRY_WORDS; }
+extern "C" int sc_isect_bin_bucket_capacity(void) { return SS_MAX_CAP; }
 
 extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, const float* depths, int C, int N,
                                   int tile_size,

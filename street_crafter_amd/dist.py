@@ -66,7 +66,7 @@ def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
         raise ValueError(f"rounding must be one of {sorted(ROUNDING)}, got {rounding!r}")
     if (acc is None) != (sky_rgb_chw is None):
         raise ValueError("acc and sky_rgb_chw go together (two-pass frame) or are both None")
-    x = rgb_chw.detach()
+    x = rgb_chw.detach() if rgb_chw.requires_grad else rgb_chw
     H, W = x.shape[1], x.shape[2]
     if out is None:
         out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
@@ -261,7 +261,7 @@ class FrameGatherer:
 
 
 def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,
-                   group=None, frames_in_flight: int = 2, batch: int = 8, ring: int = 3,
+                   group=None, frames_in_flight: int = 3, batch: int = 8, ring: int = 3,
                    force_collective: bool = False) -> Optional[List[torch.Tensor]]:
     """Renders frames 0..n_frames-1 across the ranks of `group` and returns them in order on `dst`
     (None elsewhere).  n_frames must be a multiple of the world size (every round is one frame per
@@ -269,8 +269,8 @@ def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst
     keyword `out`, it is handed the staging slot to write into and the copy is skipped).
 
     frames_in_flight > 1 (HIP devices only): this rank's frames alternate over that many HIP streams, so
-    the latency-bound intersection kernels of one frame run under the rasterizer of another (+20 % frames/s
-    with 2 on S-1M, identical images).  Frames are independent, every operator launches on torch's current
+    the latency-bound intersection kernels of one frame run under the rasterizer of another (+12..18 % frames/s
+    with 2 on S-1M, +2..3 % more with 3, identical images).  Frames are independent, every operator launches on torch's current
     stream, and the gather of a batch waits for the events of its frames.
     force_collective: see FrameGatherer (a world of one goes through the real gather ring)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1

@@ -88,6 +88,20 @@ class LazyTensor(torch.Tensor):
                 fill(self)
         return self
 
+    def _observe(self, contents: bool):
+        if contents:
+            self.materialize()
+            # somebody has had their hands on the contents (a read, or an in-place write: they arrive alike): whatever was
+            # cached ABOUT the contents on this object (isect_tiles files isect_offset_encode's result here) is dropped
+            self.__dict__["_sc_touched"] = True
+        else:
+            self.resolve_shape()
+
+    @property
+    def untouched(self) -> bool:
+        """True while no torch operation has seen the contents (reads and in-place writes alike)."""
+        return not self.__dict__.get("_sc_touched", False)
+
     def plain(self) -> torch.Tensor:
         """The materialized contents as an ordinary tensor (same storage)."""
         self.materialize()
@@ -120,11 +134,11 @@ class LazyTensor(torch.Tensor):
             contents = not _is_metadata(func)
             for a in list(args) + list(kwargs.values()):
                 if isinstance(a, LazyTensor):
-                    a.materialize() if contents else a.resolve_shape()
+                    a._observe(contents)
                 elif isinstance(a, (list, tuple)):
                     for b in a:
                         if isinstance(b, LazyTensor):
-                            b.materialize() if contents else b.resolve_shape()
+                            b._observe(contents)
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **kwargs)
         # results are ordinary tensors (views of the filled buffer included)

@@ -55,6 +55,9 @@ def _stream(t: Tensor):
 
 
 def _req(t: Tensor, name: str, dtype=torch.float32):
+    # (the common case first: small frames are bound by the host time of these wrappers)
+    if type(t) is Tensor and t.dtype is dtype and t.is_cuda and t.is_contiguous():
+        return t
     if not isinstance(t, Tensor):
         raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
     if not t.is_cuda:
@@ -387,6 +390,7 @@ _PINNED_META = threading.local()   # .slots: device index -> [pinned int64[8] th
 
 
 _DEFER_ISECT = {"on": True}
+_BUCKET_CAP = {}       # "v": sc_isect_bin_bucket_capacity()
 
 
 def set_deferred_isect(enabled: bool) -> bool:
@@ -586,7 +590,17 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
                 _BIN_LAST_META.pop(old, None)
         hist.append((n_isects, n_records, max_super))
         mi, mr, ms = map(max, zip(*hist))
-        _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms + ms // 8 + 64)
+        ms_pred = ms + ms // 8 + 64
+        # (head-room alone must not cross the capacity of the one-workgroup bucket sort: provisioned above it, every
+        #  frame also launches the split kernel and ~10 k idle segment workgroups -- 8-10 us at the training resolution,
+        #  whose largest bucket sits just below it.  A frame that does exceed it fails the device-side check and is
+        #  relaunched with exact sizes, and the history then provisions for it.)
+        cap1 = _BUCKET_CAP.get("v")
+        if cap1 is None:
+            cap1 = _BUCKET_CAP["v"] = int(lib.sc_isect_bin_bucket_capacity())
+        if ms <= cap1 < ms_pred:
+            ms_pred = cap1
+        _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms_pred)
         return n_isects, ids, fids
 
     def make_fill(get_flat, n_isects_of):
@@ -670,9 +684,13 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     lib = _lib.load()
     cached = getattr(isect_ids, "_sc_offsets", None)
-    if cached is not None and cached[1:] == (int(n_cameras), int(tile_width), int(tile_height),
-                                              isect_ids._version):
-        return cached[0]
+    if cached is not None and cached[1:4] == (int(n_cameras), int(tile_width), int(tile_height)):
+        # still the keys isect_tiles produced?  A LazyTensor knows whether anything has seen its contents (no torch
+        # call needed to ask: an attribute read through a tensor subclass costs ~4 us of host time); an ordinary
+        # tensor (eager keys) is checked by its version counter
+        if (isect_ids.__dict__.get("_sc_touched") is None if type(isect_ids) is _LazyTensor
+                else isect_ids._version == cached[4]):
+            return cached[0]
     isect_ids = _req(isect_ids, "isect_ids", torch.int64)
     dev = isect_ids.device
     offsets = torch.empty((n_cameras, tile_height, tile_width), dtype=torch.int32, device=dev)
@@ -751,11 +769,20 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 # ------------------------------------------------------------------------------------------
 # a9 rasterize_to_pixels  (renderer.py:267-280)
 # ------------------------------------------------------------------------------------------
+_SCHED_SIZES = {}      # tiles -> (words of the work-hint buffer, items of the dispatch list)
+
+
 def _sched_of(isect_offsets, n_tiles):
     """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
     sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
-    if (sched is None or sched[1].numel() != _lib.load().sc_view_slots() * n_tiles or sched[0].device != isect_offsets.device
-            or sched[0].numel() != _lib.load().sc_tile_order_len(n_tiles)):
+    if sched is None:
+        return None, None
+    want = _SCHED_SIZES.get(n_tiles)
+    if want is None:       # (two foreign calls per frame otherwise)
+        if len(_SCHED_SIZES) > 64:
+            _SCHED_SIZES.clear()
+        want = _SCHED_SIZES[n_tiles] = (_lib.load().sc_view_slots() * n_tiles, _lib.load().sc_tile_order_len(n_tiles))
+    if sched[1].numel() != want[0] or sched[0].device != isect_offsets.device or sched[0].numel() != want[1]:
         return None, None
     return sched
 

@@ -20,6 +20,12 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 1600     # the reference trains a
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1066
 STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = "cuda"
+if os.environ.get("SC_NO_CAP_CLAMP"):      # A/B: predicted bucket capacity with its head-room, whatever it crosses (before the clamp)
+    from street_crafter_amd import rendering as _r
+    _r._BUCKET_CAP["v"] = 1 << 40
+if os.environ.get("SC_DEFER") == "0":      # A/B: isect_tiles waits for the counts itself
+    from street_crafter_amd import rendering as _r
+    _r.set_deferred_isect(False)
 if os.environ.get("SC_SCENE") == "street":
     from street_crafter_amd.scenes import make_street_scene
     scene = make_street_scene(N)[0].to(dev)
