@@ -772,6 +772,35 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 _SCHED_SIZES = {}      # tiles -> (words of the work-hint buffer, items of the dispatch list)
 
 
+def reset_state(device=None) -> dict:
+    """Forgets everything the operators remember BETWEEN calls -- the size predictions and their history, the
+    rasterizer's per-view work hints and view registries, the last counts -- for `device` (an index or torch.device;
+    None = all devices).  None of it is ever needed for a correct result (every piece is a hint that the kernels verify
+    or that only orders work); a long-running process that is done with a scene may call this to hand the hint buffers
+    (32 B x tiles per frame shape, at most 8 shapes) back, and tests use it to start from a cold state.  The A/B
+    switches (set_tile_order, set_deferred_isect, ...) are not state and keep their values.  Call it between frames:
+    an isect_tiles call whose outputs have not been looked at yet is settled first.
+    -> how many entries of each table were dropped."""
+    idx = None if device is None else (device if isinstance(device, int) else torch.device(device).index)
+    slots = getattr(_PINNED_META, "slots", None) or {}
+    for d, slot in slots.items():
+        if (idx is None or d == idx) and len(slot) > 4 and slot[4] is not None:
+            pend, slot[4] = slot[4](), None
+            if pend is not None:
+                try:
+                    pend.resolve()
+                except Exception:      # noqa: BLE001  (stays on the pending call's own tensors)
+                    pass
+    dropped = {}
+    for name, table in (("predictions", _BIN_PREDICTION), ("history", _BIN_HISTORY), ("last_meta", _BIN_LAST_META),
+                        ("tile_work", _TILE_WORK), ("view_registry", _VIEW_REGISTRY)):
+        keys = [k for k in table if idx is None or (k[0] if isinstance(k, tuple) else k) == idx]
+        for k in keys:
+            table.pop(k, None)
+        dropped[name] = len(keys)
+    return dropped
+
+
 def _sched_of(isect_offsets, n_tiles):
     """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
     sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
