@@ -453,7 +453,9 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     rasterization() forward never reads it).  Host threads do not serialise each other: the count phase reports
     its sizes through a pinned slot + sequence number per (host thread, device), and the wait for it releases
     the GIL (sc_wait_i64) -- a host that renders two frames in flight from two threads keeps launching one frame
-    while it waits for the other's counts (dist.render_sharded(host_threads=True)).
+    while it waits for the other's counts (tests/test_gpu_parity.py::test_two_host_threads_render_on_one_device).
+    defer: see set_deferred_isect (the wait, the check of the predicted launch and the outputs' lengths move to the first
+    observation of the outputs; only the public isect_tiles asks for it).
     `tiles_per_gauss`: None = allocated here (the compiled binding layer allocates every output of the count phase
     in its one call)."""
     dev = means2d.device
