@@ -468,3 +468,18 @@ def test_compiled_binding_layer_loads_and_refuses_cpu_tensors(lib):
     finally:
         _lib.set_fast_binding(prev)
     assert _lib.fast() is fast
+
+
+def test_setup_py_names_the_three_packages():
+    """setup.py (the editable install that replaces the reference's `pip install gsplat` / simple-knn steps) lists the
+    package names the reference imports; nothing is installed or built by this test."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "setup.py"), "--name", "--version"], capture_output=True,
+                         text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert out.stdout.split()[:1] == ["street_crafter_amd"]
+    from setuptools import find_packages
+    pk = set(find_packages(where=ROOT, include=["street_crafter_amd", "street_crafter_amd.*", "gsplat", "gsplat.*",
+                                                "simple_knn", "simple_knn.*"]))
+    assert {"gsplat", "simple_knn", "street_crafter_amd"} <= pk
