@@ -735,9 +735,11 @@ def run_rank(args):
             def train_step(fwd_ev=None, bwd_ev=None):
                 for t in tparams:
                     t.grad = None
-                out = render_gaussians(tscene, tcam, mode="train", stage_events=fwd_ev, return_intermediates=fwd_ev is not None)
+                # (the probe is set BEFORE the forward: a probed step runs the Python autograd.Functions, whose backward
+                #  records the events; the timed steps run the C++ ones of the binding layer)
                 prev = rendering.set_backward_probe(bwd_ev)
                 try:
+                    out = render_gaussians(tscene, tcam, mode="train", stage_events=fwd_ev, return_intermediates=fwd_ev is not None)
                     ((out["rgb"] - target).abs().mean() + 0.01 * out["acc"].mean()).backward()
                 finally:
                     rendering.set_backward_probe(prev)

@@ -43,9 +43,10 @@ inline at::TensorOptions u8(const Tensor& like) { return like.options().dtype(at
 
 // ---- a1 ---------------------------------------------------------------------------------------------------
 // -> (rc, radii, means2d, depths, conics, compensations | None)
-py::tuple projection_fwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
-                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, double near_plane,
-                         double far_plane, double radius_clip, bool calc_comp, int64_t stream) {
+struct ProjOutT { int rc; Tensor radii, means2d, depths, conics; OptT comps; };
+ProjOutT projection_fwd_c(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                          const Tensor& Ks, int64_t width, int64_t height, double eps2d, double near_plane,
+                          double far_plane, double radius_clip, bool calc_comp, int64_t stream) {
     req(means, at::kFloat, "means"); req(quats, at::kFloat, "quats"); req(scales, at::kFloat, "scales");
     req(viewmats, at::kFloat, "viewmats"); req(Ks, at::kFloat, "Ks");
     const int64_t C = viewmats.size(0), N = means.size(0);
@@ -59,14 +60,22 @@ py::tuple projection_fwd(const Tensor& means, const Tensor& quats, const Tensor&
                                      (int)height, (float)eps2d, (float)near_plane, (float)far_plane, (float)radius_clip,
                                      static_cast<int32_t*>(radii.data_ptr()), fpw(means2d), fpw(depths), fpw(conics),
                                      comps ? fpw(*comps) : nullptr, S(stream));
-    return py::make_tuple(rc, radii, means2d, depths, conics, comps);
+    return {rc, radii, means2d, depths, conics, comps};
+}
+py::tuple projection_fwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, double near_plane,
+                         double far_plane, double radius_clip, bool calc_comp, int64_t stream) {
+    ProjOutT o = projection_fwd_c(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                  radius_clip, calc_comp, stream);
+    return py::make_tuple(o.rc, o.radii, o.means2d, o.depths, o.conics, o.comps);
 }
 
 // -> (rc, v_means, v_quats, v_scales)
-py::tuple projection_bwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
-                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, const Tensor& radii,
-                         const Tensor& conics, const OptT& comps, const Tensor& v_means2d, const Tensor& v_depths,
-                         const Tensor& v_conics, const OptT& v_comps, int64_t stream) {
+struct ProjBwdT { int rc; Tensor v_means, v_quats, v_scales; };
+ProjBwdT projection_bwd_c(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                          const Tensor& Ks, int64_t width, int64_t height, double eps2d, const Tensor& radii,
+                          const Tensor& conics, const OptT& comps, const Tensor& v_means2d, const Tensor& v_depths,
+                          const Tensor& v_conics, const OptT& v_comps, int64_t stream) {
     req(v_means2d, at::kFloat, "v_means2d"); req(v_depths, at::kFloat, "v_depths"); req(v_conics, at::kFloat, "v_conics");
     if (v_comps) req(*v_comps, at::kFloat, "v_compensations");
     const int64_t C = viewmats.size(0), N = means.size(0);
@@ -75,7 +84,15 @@ py::tuple projection_bwd(const Tensor& means, const Tensor& quats, const Tensor&
                                      (int)height, (float)eps2d, ip(radii), fp(conics), fpo(comps), fp(v_means2d),
                                      fp(v_depths), fp(v_conics), fpo(v_comps), fpw(v_means), fpw(v_quats),
                                      fpw(v_scales), S(stream));
-    return py::make_tuple(rc, v_means, v_quats, v_scales);
+    return {rc, v_means, v_quats, v_scales};
+}
+py::tuple projection_bwd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                         const Tensor& Ks, int64_t width, int64_t height, double eps2d, const Tensor& radii,
+                         const Tensor& conics, const OptT& comps, const Tensor& v_means2d, const Tensor& v_depths,
+                         const Tensor& v_conics, const OptT& v_comps, int64_t stream) {
+    ProjBwdT o = projection_bwd_c(means, quats, scales, viewmats, Ks, width, height, eps2d, radii, conics, comps, v_means2d,
+                                  v_depths, v_conics, v_comps, stream);
+    return py::make_tuple(o.rc, o.v_means, o.v_quats, o.v_scales);
 }
 
 // ---- a3 (tile-bucketed route) -------------------------------------------------------------------------------
@@ -133,18 +150,24 @@ int wait_i64(int64_t addr, int64_t value, int64_t timeout_us) {
 }
 
 // ---- a6 ---------------------------------------------------------------------------------------------------
-py::tuple sh_fwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, int64_t stream) {
+struct ShFwdT { int rc; Tensor colors; };
+ShFwdT sh_fwd_c(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, int64_t stream) {
     req(dirs, at::kFloat, "dirs"); req(coeffs, at::kFloat, "coeffs");
     if (masks) req(*masks, at::kByte, "masks");
     const int64_t M = dirs.numel() / 3, K = coeffs.size(-2);
     Tensor colors = at::empty(dirs.sizes(), f32(dirs));
     const int rc = sc_sh_fwd((int)degree, fp(dirs), fp(coeffs), masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr,
                              M, (int)K, fpw(colors), S(stream));
-    return py::make_tuple(rc, colors);
+    return {rc, colors};
+}
+py::tuple sh_fwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, int64_t stream) {
+    ShFwdT o = sh_fwd_c(degree, dirs, coeffs, masks, stream);
+    return py::make_tuple(o.rc, o.colors);
 }
 
-py::tuple sh_bwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, const Tensor& v_colors,
-                 bool need_dirs, int64_t stream) {
+struct ShBwdT { int rc; Tensor v_coeffs; OptT v_dirs; };
+ShBwdT sh_bwd_c(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, const Tensor& v_colors,
+                bool need_dirs, int64_t stream) {
     req(v_colors, at::kFloat, "v_colors");
     const int64_t M = dirs.numel() / 3, K = coeffs.size(-2);
     Tensor v_coeffs = at::empty_like(coeffs);
@@ -152,15 +175,21 @@ py::tuple sh_bwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const
     if (need_dirs) v_dirs = at::empty_like(dirs);
     const int rc = sc_sh_bwd((int)degree, fp(dirs), fp(coeffs), masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr,
                              M, (int)K, fp(v_colors), fpw(v_coeffs), v_dirs ? fpw(*v_dirs) : nullptr, S(stream));
-    return py::make_tuple(rc, v_coeffs, v_dirs);
+    return {rc, v_coeffs, v_dirs};
+}
+py::tuple sh_bwd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, const Tensor& v_colors,
+                 bool need_dirs, int64_t stream) {
+    ShBwdT o = sh_bwd_c(degree, dirs, coeffs, masks, v_colors, need_dirs, stream);
+    return py::make_tuple(o.rc, o.v_coeffs, o.v_dirs);
 }
 
 // ---- a9 / a11 ------------------------------------------------------------------------------------------------
 // -> (rc, render_colors, render_alphas, last_ids | None)
-py::tuple rasterize_fwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
-                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
-                        const Tensor& offsets, const Tensor& flatten_ids, bool want_last, const OptT& order,
-                        const OptT& work, int64_t stream) {
+struct RasterFwdT { int rc; Tensor colors, alphas; OptT last; };
+RasterFwdT rasterize_fwd_c(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                           const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                           const Tensor& offsets, const Tensor& flatten_ids, bool want_last, const OptT& order,
+                           const OptT& work, int64_t stream) {
     req(means2d, at::kFloat, "means2d"); req(conics, at::kFloat, "conics"); req(colors, at::kFloat, "colors");
     req(opacities, at::kFloat, "opacities"); req(offsets, at::kInt, "isect_offsets"); req(flatten_ids, at::kInt, "flatten_ids");
     const int64_t C = opacities.size(0), N = opacities.size(1), D = colors.size(-1);
@@ -176,16 +205,25 @@ py::tuple rasterize_fwd(const Tensor& means2d, const Tensor& conics, const Tenso
                                     last ? static_cast<int32_t*>(last->data_ptr()) : nullptr,
                                     order ? ip(*order) : nullptr, work ? static_cast<int32_t*>(work->data_ptr()) : nullptr,
                                     S(stream));
-    return py::make_tuple(rc, rc_, ra, last);
+    return {rc, rc_, ra, last};
+}
+py::tuple rasterize_fwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                        const Tensor& offsets, const Tensor& flatten_ids, bool want_last, const OptT& order,
+                        const OptT& work, int64_t stream) {
+    RasterFwdT o = rasterize_fwd_c(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size, offsets,
+                                   flatten_ids, want_last, order, work, stream);
+    return py::make_tuple(o.rc, o.colors, o.alphas, o.last);
 }
 
 // ONE zero-filled buffer for the five gradient outputs (the kernel accumulates with float atomics).
 // -> (rc, v_means2d, v_conics, v_colors, v_opacities, v_means2d_abs | None)
-py::tuple rasterize_bwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
-                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
-                        const Tensor& offsets, const Tensor& flatten_ids, const Tensor& render_alphas, const Tensor& last_ids,
-                        const Tensor& v_render_colors, const Tensor& v_render_alphas, bool absgrad, const OptT& order,
-                        int64_t stream) {
+struct RasterBwdT { int rc; Tensor v_m, v_c, v_col, v_o; OptT v_abs; };
+RasterBwdT rasterize_bwd_c(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                           const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                           const Tensor& offsets, const Tensor& flatten_ids, const Tensor& render_alphas, const Tensor& last_ids,
+                           const Tensor& v_render_colors, const Tensor& v_render_alphas, bool absgrad, const OptT& order,
+                           int64_t stream) {
     req(v_render_colors, at::kFloat, "v_render_colors"); req(v_render_alphas, at::kFloat, "v_render_alphas");
     req(last_ids, at::kInt, "last_ids");
     const int64_t C = opacities.size(0), N = opacities.size(1), D = colors.size(-1), CN = C * N;
@@ -205,7 +243,16 @@ py::tuple rasterize_bwd(const Tensor& means2d, const Tensor& conics, const Tenso
                                     flatten_ids.numel(), fp(render_alphas), ip(last_ids), fp(v_render_colors),
                                     fp(v_render_alphas), v_abs ? fpw(*v_abs) : nullptr, fpw(v_m), fpw(v_c), fpw(v_col),
                                     fpw(v_o), order ? ip(*order) : nullptr, S(stream));
-    return py::make_tuple(rc, v_m, v_c, v_col, v_o, v_abs);
+    return {rc, v_m, v_c, v_col, v_o, v_abs};
+}
+py::tuple rasterize_bwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                        const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                        const Tensor& offsets, const Tensor& flatten_ids, const Tensor& render_alphas, const Tensor& last_ids,
+                        const Tensor& v_render_colors, const Tensor& v_render_alphas, bool absgrad, const OptT& order,
+                        int64_t stream) {
+    RasterBwdT o = rasterize_bwd_c(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size, offsets,
+                                   flatten_ids, render_alphas, last_ids, v_render_colors, v_render_alphas, absgrad, order, stream);
+    return py::make_tuple(o.rc, o.v_m, o.v_c, o.v_col, o.v_o, o.v_abs);
 }
 
 // ---- the fused forward behind gsplat.rendering.rasterization() --------------------------------------
@@ -255,6 +302,167 @@ py::tuple rasterize_fwd_packed(const Tensor& records, const OptT& backgrounds, i
     return py::make_tuple(rc, rc_, ra);
 }
 
+// ---- the three differentiable operators as C++ autograd functions ------------------------------------------------
+// The training step (train.py:236) is bound by HOST time on a busy box (BENCH_r02: 786 steps/s on the driver's box, 1060 on a
+// quiet one, same kernels): per step torch.autograd.Function.apply costs ~15 us of Python per operator on the way forward
+// and a Python call from the autograd engine's thread (GIL, argument wrapping) per operator on the way back.  Here forward
+// and backward are the C++ cores above: no Python frame, and in the backward the GIL is taken only to ask torch for the
+// current raw stream (the engine runs a backward on its forward's stream) and for gsplat's `.absgrad` contract (one
+// attribute assignment on the caller's tensor object).  The Python autograd.Functions of rendering.py stay: they are the
+// ctypes path's, the A/B (`rendering.set_native_autograd(False)`), and what runs while a backward probe is set.
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct PyRef : torch::CustomClassHolder {      // a Python object kept alive by an autograd node
+    PyObject* p;
+    explicit PyRef(PyObject* o) : p(o) { Py_XINCREF(p); }
+    ~PyRef() override {
+        if (p && Py_IsInitialized()) { py::gil_scoped_acquire g; Py_DECREF(p); }
+    }
+};
+inline c10::IValue keep(const py::object& o) { return c10::IValue::make_capsule(c10::make_intrusive<PyRef>(o.ptr())); }
+inline PyObject* kept(const c10::IValue& v) { return c10::static_intrusive_pointer_cast<PyRef>(v.toCapsule())->p; }
+// torch._C._cuda_getCurrentRawStream(device index), asked under the GIL
+inline int64_t raw_stream_of(const c10::IValue& stream_fn, const Tensor& like) {
+    py::gil_scoped_acquire g;
+    return py::reinterpret_borrow<py::object>(kept(stream_fn))((int)like.get_device()).cast<int64_t>();
+}
+inline void check_rc(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, what, " failed: ", sc_error_string(rc), " (code ", rc, ")");
+}
+inline Tensor or_empty(const OptT& t, const Tensor& like) { return t.has_value() ? *t : at::empty({0}, f32(like)); }
+
+struct ProjectionFn : public torch::autograd::Function<ProjectionFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& means, const Tensor& quats, const Tensor& scales,
+                                 const Tensor& viewmats, const Tensor& Ks, int64_t width, int64_t height, double eps2d,
+                                 double near_plane, double far_plane, double radius_clip, bool calc_comp,
+                                 py::object stream_fn) {
+        const c10::IValue sf = keep(stream_fn);
+        ProjOutT o = projection_fwd_c(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                      radius_clip, calc_comp, raw_stream_of(sf, means));
+        check_rc(o.rc, "sc_projection_fwd");
+        ctx->save_for_backward({means, quats, scales, viewmats, Ks, o.radii, o.conics, or_empty(o.comps, means)});
+        ctx->saved_data["w"] = width; ctx->saved_data["h"] = height; ctx->saved_data["eps"] = eps2d;
+        ctx->saved_data["comp"] = calc_comp; ctx->saved_data["sf"] = sf;
+        ctx->mark_non_differentiable({o.radii});
+        if (calc_comp) return {o.radii, o.means2d, o.depths, o.conics, *o.comps};
+        return {o.radii, o.means2d, o.depths, o.conics};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const Tensor &means = sv[0], &quats = sv[1], &scales = sv[2], &viewmats = sv[3], &Ks = sv[4];
+        const bool has_comp = ctx->saved_data["comp"].toBool();
+        const int64_t C = viewmats.size(0), N = means.size(0);
+        auto z = [&](const Tensor& t, at::IntArrayRef shape) {
+            return t.defined() ? t.contiguous() : at::zeros(shape, f32(means));
+        };
+        const Tensor v_m2 = z(g[1], {C, N, 2}), v_d = z(g[2], {C, N}), v_c = z(g[3], {C, N, 3});
+        OptT v_comp, comps;
+        if (has_comp) { v_comp = z(g.size() > 4 ? g[4] : Tensor(), {C, N}); comps = sv[7]; }
+        ProjBwdT o = projection_bwd_c(means, quats, scales, viewmats, Ks, ctx->saved_data["w"].toInt(),
+                                      ctx->saved_data["h"].toInt(), ctx->saved_data["eps"].toDouble(), sv[5], sv[6], comps,
+                                      v_m2, v_d, v_c, v_comp, raw_stream_of(ctx->saved_data["sf"], means));
+        check_rc(o.rc, "sc_projection_bwd");
+        return {ctx->needs_input_grad(0) ? o.v_means : Tensor(), ctx->needs_input_grad(1) ? o.v_quats : Tensor(),
+                ctx->needs_input_grad(2) ? o.v_scales : Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+struct ShFn : public torch::autograd::Function<ShFn> {
+    static Tensor forward(AutogradContext* ctx, int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks,
+                          py::object stream_fn) {
+        const c10::IValue sf = keep(stream_fn);
+        ShFwdT o = sh_fwd_c(degree, dirs, coeffs, masks, raw_stream_of(sf, dirs));
+        check_rc(o.rc, "sc_sh_fwd");
+        ctx->save_for_backward({dirs, coeffs, or_empty(masks, dirs)});
+        ctx->saved_data["deg"] = degree; ctx->saved_data["mask"] = masks.has_value(); ctx->saved_data["sf"] = sf;
+        return o.colors;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        OptT masks;
+        if (ctx->saved_data["mask"].toBool()) masks = sv[2];
+        const Tensor v_colors = g[0].defined() ? g[0].contiguous() : at::zeros_like(sv[0]);
+        // (needs_input_grad counts the TENSOR inputs of forward: dirs 0, coeffs 1)
+        ShBwdT o = sh_bwd_c(ctx->saved_data["deg"].toInt(), sv[0], sv[1], masks, v_colors, ctx->needs_input_grad(0),
+                            raw_stream_of(ctx->saved_data["sf"], sv[0]));
+        check_rc(o.rc, "sc_sh_bwd");
+        return {Tensor(), o.v_dirs.has_value() ? *o.v_dirs : Tensor(), ctx->needs_input_grad(1) ? o.v_coeffs : Tensor(),
+                Tensor(), Tensor()};
+    }
+};
+
+struct RasterFn : public torch::autograd::Function<RasterFn> {
+    static variable_list forward(AutogradContext* ctx, const Tensor& means2d, const Tensor& conics, const Tensor& colors,
+                                 const Tensor& opacities, const OptT& backgrounds, const OptT& masks, int64_t width,
+                                 int64_t height, int64_t tile_size, const Tensor& offsets, const Tensor& flatten_ids,
+                                 bool absgrad, const OptT& order, const OptT& work, py::object absgrad_target,
+                                 py::object stream_fn) {
+        const c10::IValue sf = keep(stream_fn);
+        const bool needs_bwd = means2d.requires_grad() || conics.requires_grad() || colors.requires_grad() ||
+                               opacities.requires_grad() || (backgrounds.has_value() && backgrounds->requires_grad());
+        RasterFwdT o = rasterize_fwd_c(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size, offsets,
+                                       flatten_ids, needs_bwd, order, work, raw_stream_of(sf, means2d));
+        check_rc(o.rc, "sc_rasterize_fwd");
+        ctx->save_for_backward({means2d, conics, colors, opacities, or_empty(backgrounds, means2d),
+                                masks.has_value() ? *masks : at::empty({0}, u8(means2d)), offsets, flatten_ids, o.alphas,
+                                o.last.has_value() ? *o.last : at::empty({0}, i32(means2d)),
+                                order.has_value() ? *order : at::empty({0}, i32(means2d))});
+        ctx->saved_data["w"] = width; ctx->saved_data["h"] = height; ctx->saved_data["tile"] = tile_size;
+        ctx->saved_data["abs"] = absgrad; ctx->saved_data["bg"] = backgrounds.has_value();
+        ctx->saved_data["mask"] = masks.has_value(); ctx->saved_data["order"] = order.has_value();
+        ctx->saved_data["sf"] = sf; ctx->saved_data["target"] = keep(absgrad_target);
+        return {o.colors, o.alphas};
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const Tensor &means2d = sv[0], &colors = sv[2], &render_alphas = sv[8];
+        OptT bg, masks, order;
+        if (ctx->saved_data["bg"].toBool()) bg = sv[4];
+        if (ctx->saved_data["mask"].toBool()) masks = sv[5];
+        if (ctx->saved_data["order"].toBool()) order = sv[10];
+        const bool absgrad = ctx->saved_data["abs"].toBool();
+        const Tensor v_rc = g[0].defined() ? g[0].contiguous()
+                                           : at::zeros({render_alphas.size(0), render_alphas.size(1), render_alphas.size(2),
+                                                        colors.size(-1)}, f32(means2d));
+        const Tensor v_ra = g[1].defined() ? g[1].contiguous() : at::zeros_like(render_alphas);
+        RasterBwdT o = rasterize_bwd_c(means2d, sv[1], colors, sv[3], bg, masks, ctx->saved_data["w"].toInt(),
+                                       ctx->saved_data["h"].toInt(), ctx->saved_data["tile"].toInt(), sv[6], sv[7], render_alphas,
+                                       sv[9], v_rc, v_ra, absgrad, order, raw_stream_of(ctx->saved_data["sf"], means2d));
+        check_rc(o.rc, "sc_rasterize_bwd");
+        if (absgrad && o.v_abs.has_value()) {
+            // gsplat's contract (street_gaussian_model.py:505-506): the tensor OBJECT the caller passed as means2d gets `.absgrad`
+            py::gil_scoped_acquire gil;
+            py::reinterpret_borrow<py::object>(kept(ctx->saved_data["target"])).attr("absgrad") = py::cast(*o.v_abs);
+        }
+        Tensor v_bg;
+        if (bg.has_value() && ctx->needs_input_grad(4)) v_bg = (v_rc * (1.0 - render_alphas)).sum(at::IntArrayRef({1, 2}));
+        return {o.v_m, o.v_c, o.v_col, o.v_o, v_bg, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), Tensor(),
+                Tensor(), Tensor(), Tensor(), Tensor()};
+    }
+};
+
+py::tuple projection_autograd(const Tensor& means, const Tensor& quats, const Tensor& scales, const Tensor& viewmats,
+                              const Tensor& Ks, int64_t width, int64_t height, double eps2d, double near_plane,
+                              double far_plane, double radius_clip, bool calc_comp, py::object stream_fn) {
+    variable_list o = ProjectionFn::apply(means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane,
+                                          radius_clip, calc_comp, stream_fn);
+    if (calc_comp) return py::make_tuple(o[0], o[1], o[2], o[3], o[4]);
+    return py::make_tuple(o[0], o[1], o[2], o[3]);
+}
+Tensor sh_autograd(int64_t degree, const Tensor& dirs, const Tensor& coeffs, const OptT& masks, py::object stream_fn) {
+    return ShFn::apply(degree, dirs, coeffs, masks, stream_fn);
+}
+py::tuple rasterize_autograd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                             const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                             const Tensor& offsets, const Tensor& flatten_ids, bool absgrad, const OptT& order,
+                             const OptT& work, py::object absgrad_target, py::object stream_fn) {
+    variable_list o = RasterFn::apply(means2d, conics, colors, opacities, backgrounds, masks, width, height, tile_size, offsets,
+                                      flatten_ids, absgrad, order, work, absgrad_target, stream_fn);
+    return py::make_tuple(o[0], o[1]);
+}
+
 // ---- frame export ---------------------------------------------------------------------------------------------
 int frame_composite_u8(int64_t fg_ptr, int64_t fg_stride, int64_t acc_ptr, int64_t sky_ptr, int64_t sky_stride,
                        int64_t n_pixels, int64_t rounding, const Tensor& out, int64_t stream) {
@@ -278,6 +486,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("sh_bwd", &sh_bwd);
     m.def("rasterize_fwd", &rasterize_fwd);
     m.def("rasterize_bwd", &rasterize_bwd);
+    m.def("projection_autograd", &projection_autograd);
+    m.def("sh_autograd", &sh_autograd);
+    m.def("rasterize_autograd", &rasterize_autograd);
     m.def("projection_sh_fwd", &projection_sh_fwd);
     m.def("rasterize_fwd_packed", &rasterize_fwd_packed);
     m.def("frame_composite_u8", &frame_composite_u8);

@@ -88,11 +88,34 @@ _NO_GRAD_CTX = _NoGradCtx()
 _EMPTY = {}            # device -> a zero-element tensor (placeholder for None in save_for_backward)
 
 
+def _needs_grad(*args) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(a, Tensor) and a.requires_grad for a in args)
+
+
 def _call(fn, *args):
     """fn.apply(*args), or fn.forward on a dummy context when autograd has nothing to record."""
-    if torch.is_grad_enabled() and any(isinstance(a, Tensor) and a.requires_grad for a in args):
+    if _needs_grad(*args):
         return fn.apply(*args)
     return fn.forward(_NO_GRAD_CTX, *args)
+
+
+_NATIVE_AUTOGRAD = {"on": True}
+
+
+def set_native_autograd(enabled: bool) -> bool:
+    """The three differentiable operators' autograd plumbing: True (default) = the C++ autograd functions of the compiled
+    binding layer (csrc/binding.cpp: forward and backward without a Python frame; the training step is host-bound on a busy
+    box), False = the Python torch.autograd.Functions of this module (also what the ctypes path uses and what runs while a
+    backward probe is set).  Same kernels, same gradients.  Returns the previous setting."""
+    prev, _NATIVE_AUTOGRAD["on"] = _NATIVE_AUTOGRAD["on"], bool(enabled)
+    return prev
+
+
+def _native():
+    """The compiled binding layer if ITS autograd functions are to be used for this call, else None."""
+    if not _NATIVE_AUTOGRAD["on"] or _BACKWARD_PROBE["events"] is not None or _RAW_STREAM is None:
+        return None
+    return _lib.fast()
 
 
 def _ws(nbytes: int, device) -> Tensor:
@@ -236,8 +259,14 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
     assert scales.shape == (N, 3), scales.shape
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
-    out = _call(_Projection, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
-                            far_plane, radius_clip, calc_compensations)
+    nat = _native() if _needs_grad(means, quats, scales) else None
+    if nat is not None:
+        out = nat.projection_autograd(means, quats, scales, viewmats, Ks, int(width), int(height), float(eps2d),
+                                      float(near_plane), float(far_plane), float(radius_clip), bool(calc_compensations),
+                                      _RAW_STREAM)
+    else:
+        out = _call(_Projection, means, quats, scales, viewmats, Ks, width, height, eps2d, near_plane,
+                                far_plane, radius_clip, calc_compensations)
     if N and C:
         out[1]._sc_viewmats = viewmats           # means2d carries the cameras to isect_tiles (view slots)
     if calc_compensations:
@@ -765,6 +794,9 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
             masks = masks.to(torch.uint8).contiguous()
         else:
             masks = masks.contiguous()
+    nat = _native() if _needs_grad(dirs, coeffs) else None
+    if nat is not None:
+        return nat.sh_autograd(int(degrees_to_use), dirs, coeffs, masks, _RAW_STREAM)
     return _call(_SphericalHarmonics, int(degrees_to_use), dirs, coeffs, masks)
 
 
@@ -960,6 +992,12 @@ def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opaciti
             raise RuntimeError("masks must live on a HIP device")
         masks = masks.to(torch.uint8).contiguous()
 
+    nat = _native() if _needs_grad(means2d_c, conics, colors, opacities, backgrounds) else None
+    if nat is not None:
+        order, work = _sched_of(isect_offsets, C * tw * th)
+        return nat.rasterize_autograd(means2d_c, conics, colors, opacities, backgrounds, masks, int(image_width),
+                                      int(image_height), int(tile_size), isect_offsets, flatten_ids, bool(absgrad), order,
+                                      work, caller_means2d, _RAW_STREAM)
     return _call(_Rasterize, means2d_c, conics, colors, opacities, backgrounds, masks, int(image_width),
                             int(image_height), int(tile_size), isect_offsets, flatten_ids, bool(absgrad),
                             _AbsgradTarget(caller_means2d))

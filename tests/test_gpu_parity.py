@@ -1007,6 +1007,80 @@ def test_train_mode_contract_retain_grad_and_absgrad(ops):
     assert float(sc.means.grad.abs().sum()) > 0
 
 
+def test_native_autograd_functions_equal_the_python_ones(ops):
+    """csrc/binding.cpp: the three differentiable operators as C++ autograd functions (the default when the compiled
+    binding layer is loaded) against the Python torch.autograd.Functions of rendering.py: same kernels, so the images, every
+    parameter gradient, viewspace_points.grad and .absgrad must be IDENTICAL -- with a background (its gradient too), with
+    some inputs not requiring grad, and the backward atomics' order apart (float atomics: allclose at 1e-6 of the largest
+    entry).  Also: the contract pieces the native path must keep (retain_grad on the projection's output, .absgrad on the
+    caller's tensor object, only after backward)."""
+    from harness.caller import render_gaussians
+    from street_crafter_amd import _lib, rendering
+    if _lib.fast() is None:
+        pytest.skip("compiled binding layer not loaded")
+    cam = make_camera(192, 112, 210.0, 210.0).to(DEV)
+
+    def step(native, freeze=()):
+        sc = make_scene(3000, seed=4, z_range=(1.0, 30.0), scale_range=(0.02, 0.3)).to(DEV)
+        ps = {"means": sc.means, "quats": sc.quats, "scales": sc.scales, "opacities": sc.opacities, "sh": sc.sh}
+        for k, t in ps.items():
+            t.requires_grad_(k not in freeze)
+        prev = rendering.set_native_autograd(native)
+        try:
+            out = render_gaussians(sc, cam, mode="train")
+            vp = out["viewspace_points"]
+            assert not hasattr(vp, "absgrad")                       # gsplat sets it in backward, not before
+            (out["rgb"].square().mean() + 0.1 * out["acc"].mean() + 0.01 * out["depth"].mean()).backward()
+        finally:
+            rendering.set_native_autograd(prev)
+        return out, {k: (None if t.grad is None else t.grad.clone()) for k, t in ps.items()}, vp
+
+    def close(a, b, what):
+        assert (a is None) == (b is None), what
+        if a is not None:
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 1e-6 * scale + 1e-12, (what, float((a - b).abs().max()), scale)
+
+    for freeze in ((), ("quats", "sh")):
+        o_n, g_n, vp_n = step(True, freeze)
+        o_p, g_p, vp_p = step(False, freeze)
+        assert torch.equal(o_n["rgb"], o_p["rgb"]) and torch.equal(o_n["acc"], o_p["acc"]) and torch.equal(o_n["depth"], o_p["depth"])
+        for k in g_n:
+            close(g_n[k], g_p[k], k)
+            assert (g_n[k] is None) == (k in freeze)
+        assert vp_n.grad is not None and vp_n.grad.shape == vp_p.grad.shape
+        close(vp_n.grad, vp_p.grad, "viewspace_points.grad")
+        close(vp_n.absgrad, vp_p.absgrad, "absgrad")
+        assert float(vp_n.absgrad.sum()) > 0 and bool((vp_n.absgrad >= vp_n.grad.abs() - 1e-6).all())
+    # rasterize_to_pixels with a background that requires grad, and spherical_harmonics with masks, operator by operator
+    sc = make_scene(2000, seed=9, z_range=(1.0, 20.0), scale_range=(0.03, 0.3)).to(DEV)
+    res = []
+    for native in (True, False):
+        prev = rendering.set_native_autograd(native)
+        try:
+            with torch.no_grad():
+                radii, m2, d, con, comp = ops.fully_fused_projection(sc.means, None, sc.quats, sc.scales, cam.viewmat[None], cam.K[None],
+                                                                      192, 112, near_plane=0.001, far_plane=1000.0, calc_compensations=True)
+                tpg, ids, fids = ops.isect_tiles(m2, radii, d, 16, 12, 7, n_cameras=1)
+                off = ops.isect_offset_encode(ids, 1, 12, 7)
+            g = torch.Generator(DEV).manual_seed(3)
+            cols = torch.rand(1, sc.n, 3, device=DEV, generator=g).requires_grad_(True)
+            bg = torch.rand(1, 3, device=DEV, generator=g).requires_grad_(True)
+            m2g = m2.clone().requires_grad_(True)
+            rc, ra = ops.rasterize_to_pixels(m2g, con, cols, sc.opacities[None, :, 0] * comp, 192, 112, 16, off, fids, backgrounds=bg,
+                                             absgrad=True)
+            (rc.sum() + ra.square().sum()).backward()
+            dirs = (sc.means[None] - cam.camera_center).detach().requires_grad_(True)
+            coeffs = sc.sh[None].detach().clone().requires_grad_(True)
+            c2 = ops.spherical_harmonics(1, dirs, coeffs, masks=radii > 0)
+            c2.square().sum().backward()
+            res.append((rc.detach(), ra.detach(), cols.grad, bg.grad, m2g.grad, m2g.absgrad, c2.detach(), dirs.grad, coeffs.grad))
+        finally:
+            rendering.set_native_autograd(prev)
+    for a, b, what in zip(res[0], res[1], ("rc", "ra", "v_colors", "v_backgrounds", "v_means2d", "absgrad", "sh", "v_dirs", "v_coeffs")):
+        close(a, b, what)
+
+
 @pytest.mark.parametrize("render_mode,rasterize_mode,deg,use_bg", [
     ("RGB+ED", "antialiased", 1, False),     # what render_kernel_gsplat spells out by hand
     ("RGB+ED", "classic", 3, True),

@@ -42,8 +42,8 @@ def child(which, lib, frames):
             for t in ps:
                 t.grad = None
             rec = i >= 3
+            prev = rendering.set_backward_probe(ev if rec else None)      # (before the forward: probed steps run the Python Functions)
             o = render_gaussians(sc, cam, mode="train", stage_events=ev if rec else None)
-            prev = rendering.set_backward_probe(ev if rec else None)
             ((o["rgb"] - target).abs().mean() + 0.01 * o["acc"].mean()).backward()
             rendering.set_backward_probe(prev)
     else:

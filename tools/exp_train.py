@@ -23,6 +23,9 @@ dev = "cuda"
 if os.environ.get("SC_NO_CAP_CLAMP"):      # A/B: predicted bucket capacity with its head-room, whatever it crosses (before the clamp)
     from street_crafter_amd import rendering as _r
     _r._BUCKET_CAP["v"] = 1 << 40
+if os.environ.get("SC_NATIVE_AUTOGRAD") == "0":      # A/B: the Python torch.autograd.Functions instead of the C++ ones
+    from street_crafter_amd import rendering as _r
+    _r.set_native_autograd(False)
 if os.environ.get("SC_DEFER") == "0":      # A/B: isect_tiles waits for the counts itself
     from street_crafter_amd import rendering as _r
     _r.set_deferred_isect(False)

@@ -14,6 +14,9 @@ import torch  # noqa: E402
 from harness.caller import render_gaussians  # noqa: E402
 from street_crafter_amd.scenes import make_camera, make_scene  # noqa: E402
 
+if os.environ.get("SC_NATIVE_AUTOGRAD") == "0":      # A/B: the Python torch.autograd.Functions instead of the C++ ones
+    from street_crafter_amd import rendering as _r
+    _r.set_native_autograd(False)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 W, H = 1600, 1066
 sc = make_scene(N).to("cuda")
