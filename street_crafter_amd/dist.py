@@ -23,6 +23,8 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 # uint8 quantisation of a [0,1] image, as the reference's visualizer does it:
 #   "video"      (x * 255).astype(np.uint8): the frames render_novel_view collects for the video
 #                (street_gaussian_visualizer.py:97, base_visualizer.py:37; render.py:48-49 turns
@@ -37,20 +39,25 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
 
 
 def _hwc_view(x: torch.Tensor):
-    """[3,H,W] tensor that is a permuted view of an [H,W,C>=3] image -> (that [H,W,3] view, pixel stride)
-    or None."""
+    """[3,H,W] tensor that is a permuted view of an [H,W,C>=3] image -> (x itself: its first element IS pixel (0,0)
+    channel 0 of that image, pixel stride) or None.  (Read off the strides: building the permuted view costs ~2 us of
+    host time per frame.)"""
     if x.dim() != 3 or x.shape[0] != 3:
         return None
-    hwc = x.permute(1, 2, 0)
-    H, W = hwc.shape[0], hwc.shape[1]
-    if hwc.stride(2) == 1 and hwc.stride(1) >= 3 and hwc.stride(0) == W * hwc.stride(1):
-        return hwc, hwc.stride(1)
+    s0, s1, s2 = x.stride()
+    if s0 == 1 and s2 >= 3 and s1 == x.shape[2] * s2:
+        return x, s2
     return None
 
 
+_STREAM_FN = []
+
+
 def _raw_stream(t: torch.Tensor):
-    from .rendering import _stream
-    return _stream(t)
+    if not _STREAM_FN:
+        from .rendering import _stream
+        _STREAM_FN.append(_stream)
+    return _STREAM_FN[0](t)
 
 
 def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
@@ -78,7 +85,6 @@ def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
         a = acc.detach().reshape(H, W) if acc is not None else None
         if fg is not None and (sky_rgb_chw is None or (sky is not None and a.is_contiguous()
                                                       and a.dtype == torch.float32)):
-            from . import _lib
             fast = _lib.fast()
             if fast is not None:
                 rc = fast.frame_composite_u8(fg[0].data_ptr(), fg[1], 0 if a is None else a.data_ptr(),
