@@ -88,6 +88,12 @@ extern "C" int sc_set_option(const char* key, int value) {
         g_sc_raster_split = value;
         return prev;
     }
+    if (strcmp(key, "isect_pull") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_isect_pull;
+        g_sc_isect_pull = value;
+        return prev;
+    }
     if (strcmp(key, "raster_fwd") == 0) {
         if (value != 0 && value != 3) return SC_EINVAL;
         const int prev = g_sc_raster_fwd_variant;

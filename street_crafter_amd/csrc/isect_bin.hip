@@ -54,7 +54,38 @@ struct Geo {
     int ss;                              // super-tile shift (1: 2x2 tiles, 0: super-tile == tile)
     int stw, sth, ST;                    // super-tiles
     int N;
+    int ncls;                            // > 0: the PULL route (below) with this many size classes; 0: the scatter route
 };
+
+// ---- the PULL route (round 4) -----------------------------------------------------------------------------------
+// The scatter route writes one 8-B record per (Gaussian, super-tile) into per-bucket slices of a records buffer
+// (bin_scatter_flat: LDS histogram, one global atomic per (workgroup, bucket), scattered 8-B stores) and the sort
+// reads them back.  The pull route has no records buffer and no scatter launch: the bucket's own sort workgroup
+// GATHERS its records from the spatially sorted payload.  For that the visible Gaussians are counting-sorted by
+// (size class, anchor row, anchor column) instead of by centre super-tile: anchor = top-left super-tile of the
+// rectangle, class c = smallest c with pull_size(c) >= max(width, height) of the super-tile rectangle
+// (half-octave sizes 1 2 3 4 6 8 12 16 24 32 48 64 ...).  A Gaussian of class c can only cover bucket (bx, by) if
+// its anchor lies in the s x s window (bx - s, bx] x (by - s, by], s = pull_size(c): per class that is s runs of
+// consecutive keys (one per anchor row), i.e. sum of the sizes (~190 for a 60 x 40 grid) contiguous runs of the
+// payload per bucket, of which 1 / 1.4 (S-1M, street) .. 1 / 1.7 (a sky set) are hits (tools/an_pull.py).
+constexpr int PULL_MAX_CLS = 16;
+struct PullTab { int nrows; int row0[PULL_MAX_CLS + 1]; };     // row0[c] = first window row of class c (host-built)
+
+__host__ __device__ __forceinline__ int pull_size(int c) {      // 1 2 3 4 6 8 12 16 24 32 48 64 96 128 192 256
+    if (c < 4) return c + 1;
+    const int k = c - 4;
+    return (k & 1) ? (8 << (k >> 1)) : (6 << (k >> 1));
+}
+// smallest c with pull_size(c) >= m (m >= 1), clamped to ncls - 1 (the last class's window is the whole grid)
+__device__ __forceinline__ int pull_class(int m, int ncls) {
+    int c;
+    if (m <= 4) c = m - 1;
+    else {
+        const int p = 31 - __clz(m - 1);                 // floor(log2(m - 1)) >= 2
+        c = 4 + 2 * (p - 2) + (((m - 1) >= (6 << (p - 2))) ? 1 : 0);
+    }
+    return c < ncls - 1 ? c : ncls - 1;
+}
 
 // identical to isect.hip's tile_rect
 __device__ __forceinline__ Rect tile_rect(float mx, float my, int radius, float tile_size,
@@ -180,7 +211,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
     }
     const int nt = C * (g.tile_height + 1) * (g.tile_width + 1);
     const int ns = g.ss ? C * (g.sth + 1) * (g.stw + 1) : 0;
-    const int nc = C * g.ST;
+    // pull route: the histogram is over (camera, size class, anchor) keys, kept as 16-bit halves in LDS (a workgroup
+    // has at most 8192 Gaussians)
+    const int nc = g.ncls ? (C * g.ncls * g.ST + 1) >> 1 : C * g.ST;
     int* dt = LOCAL ? lds_i : dgrid_t;
     int* ds = LOCAL ? lds_i + nt : dgrid_s;
     int* ch = LOCAL ? lds_i + nt + ns : reinterpret_cast<int*>(chist);
@@ -212,14 +245,28 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(
             atomicAdd(&d[s.y0 * w + s.x0], 1);  atomicAdd(&d[s.y0 * w + s.x1], -1);
             atomicAdd(&d[s.y1 * w + s.x0], -1); atomicAdd(&d[s.y1 * w + s.x1], 1);
         }
-        const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
-        atomicAdd(&ch[cam * g.ST + cy * g.stw + cx], 1);
+        if (g.ncls) {
+            const int key = ((cam * g.ncls + pull_class(max(s.x1 - s.x0, s.y1 - s.y0), g.ncls)) * g.sth + s.y0) * g.stw + s.x0;
+            if (LOCAL) atomicAdd(&ch[key >> 1], 1 << ((key & 1) << 4));
+            else atomicAdd(&chist[key], 1u);
+        } else {
+            const int cx = (s.x0 + s.x1 - 1) >> 1, cy = (s.y0 + s.y1 - 1) >> 1;
+            atomicAdd(&ch[cam * g.ST + cy * g.stw + cx], 1);
+        }
     }
     if (!LOCAL) return;
     __syncthreads();
     for (int i = threadIdx.x; i < nt; i += BIN_THREADS) { const int v = dt[i]; if (v) atomicAdd(&dgrid_t[i], v); }
     for (int i = threadIdx.x; i < ns; i += BIN_THREADS) { const int v = ds[i]; if (v) atomicAdd(&dgrid_s[i], v); }
-    for (int i = threadIdx.x; i < nc; i += BIN_THREADS) { const int v = ch[i]; if (v) atomicAdd(&chist[i], (unsigned)v); }
+    if (g.ncls) {
+        for (int i = threadIdx.x; i < nc; i += BIN_THREADS) {
+            const unsigned v = (unsigned)ch[i];
+            if (v & 0xffffu) atomicAdd(&chist[2 * i], v & 0xffffu);
+            if (v >> 16) atomicAdd(&chist[2 * i + 1], v >> 16);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nc; i += BIN_THREADS) { const int v = ch[i]; if (v) atomicAdd(&chist[i], (unsigned)v); }
+    }
 }
 
 // block-wide exclusive scan helper (1024 threads): returns the exclusive prefix of `sum`, the
@@ -357,7 +404,7 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ means2d,
     const int32_t* __restrict__ radii, int64_t CN, Geo g, float tile_size, int n_sbuckets,
     const float* __restrict__ depths, const unsigned* __restrict__ chist, unsigned* __restrict__ ccursor,
-    uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, ScanJobs jobs,
+    uint4* __restrict__ sorted, int64_t* __restrict__ cmeta, int32_t* __restrict__ cstart, ScanJobs jobs,
     unsigned* __restrict__ scans_done, int64_t* __restrict__ meta_dev, int64_t* meta_mirror, int64_t seq,
     const unsigned* __restrict__ whint, const unsigned* __restrict__ wstat, int32_t* __restrict__ tile_order,
     int n_tiles_total, int staged, int split_pct, int want_bwd SC_DIAG_PARAM(odbg)) {
@@ -547,6 +594,54 @@ __global__ __launch_bounds__(BIN_THREADS) void center_scatter_kernel(
         return;
     }
     const int cblock = (int)blockIdx.x - 3;
+    if (g.ncls) {
+        // PULL route: counting sort by (camera, size class, anchor row, anchor column).  Every workgroup scans the key
+        // histogram itself (as the scatter route's workgroups scan the centre histogram: a scan of its own would be one more
+        // dependent launch); a Gaussian's slot is its key's start plus a global running cursor (in arrival order nearly every
+        // Gaussian of a workgroup has a key of its own, so a per-workgroup LDS aggregation would save nothing).
+        const int nkeys = n_sbuckets * g.ncls;
+        unsigned* cst = lds;                 // [nkeys]
+        for (int i = threadIdx.x; i < nkeys; i += BIN_THREADS) cst[i] = chist[i];
+        __syncthreads();
+        const int per = ((nkeys + BIN_THREADS - 1) / BIN_THREADS) | 1;      // odd: the threads' strides hit distinct banks
+        const int beg = min((int)threadIdx.x * per, nkeys), end = min(beg + per, nkeys);
+        long long sum = 0;
+        for (int i = beg; i < end; ++i) sum += cst[i];
+        long long tot;
+        unsigned mx;
+        long long run = block_scan_1024(sum, 0u, &tot, &mx, wave_tot, wave_max);
+        for (int i = beg; i < end; ++i) { const unsigned c = cst[i]; cst[i] = (unsigned)run; run += c; }
+        if (cblock == 0 && threadIdx.x == 0) { cmeta[0] = tot; cmeta[1] = 0; }   // number of visible Gaussians
+        __syncthreads();
+        if (cblock == 0) {                   // the key starts, for the pulling workgroups of the sort launch
+            for (int i = threadIdx.x; i < nkeys; i += BIN_THREADS) cstart[i] = (int32_t)cst[i];
+            if (threadIdx.x == 0) cstart[nkeys] = (int32_t)tot;
+        }
+        const int64_t base = (int64_t)cblock * BIN_GPB;
+        int key[BIN_GPT];
+        uint4 pay[BIN_GPT];
+#pragma unroll
+        for (int k = 0; k < BIN_GPT; ++k) {
+            const int64_t i = base + (int64_t)k * BIN_THREADS + threadIdx.x;
+            key[k] = -1;
+            pay[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < CN && tiles_per_gauss[i] > 0) {
+                const float2 m = *reinterpret_cast<const float2*>(means2d + i * 2);
+                const Rect r = tile_rect(m.x, m.y, radii[i], tile_size, g.tile_width, g.tile_height);
+                const Rect s = super_rect(r, g.ss);
+                key[k] = (((int)(i / g.N) * g.ncls + pull_class(max(s.x1 - s.x0, s.y1 - s.y0), g.ncls)) * g.sth + s.y0) * g.stw + s.x0;
+                pay[k] = make_uint4((unsigned)r.x0 | ((unsigned)r.x1 << 16), (unsigned)r.y0 | ((unsigned)r.y1 << 16),
+                                    __float_as_uint(depths[i]), (unsigned)i);
+            }
+        }
+        unsigned slot[BIN_GPT];
+#pragma unroll
+        for (int k = 0; k < BIN_GPT; ++k) slot[k] = key[k] >= 0 ? cst[key[k]] + atomicAdd(&ccursor[key[k]], 1u) : 0u;
+#pragma unroll
+        for (int k = 0; k < BIN_GPT; ++k)
+            if (key[k] >= 0 && slot[k] < (unsigned)CN) sorted[slot[k]] = pay[k];
+        return;
+    }
     unsigned* hist = lds;                    // [n_sbuckets]
     unsigned* gbase = lds + n_sbuckets;      // [n_sbuckets]
     unsigned* cst = lds + 2 * n_sbuckets;    // [n_sbuckets] first slot of each centre bucket in the spatial order
@@ -841,6 +936,107 @@ __device__ __forceinline__ void emit_tiles(const unsigned long long* __restrict_
     }
 }
 
+// ---- PULL route: a bucket's workgroup gathers its own records ---------------------------------------------------
+// LDS words the gather needs: seg_start[nrows], seg_off[nrows + 1], the hit counter
+__host__ __device__ inline size_t pull_lds_words(int nrows) { return (size_t)(2 * nrows + 4); }
+
+__device__ __forceinline__ unsigned pull_tile_mask(int x0, int x1, int y0, int y1, int bx, int by, int ss) {
+    // (x0, x1, y0, y1): the Gaussian's TILE rectangle; (bx, by): the super-tile.  0 = the rectangle misses the bucket
+    if (!ss) return (x0 <= bx && bx < x1 && y0 <= by && by < y1) ? 1u : 0u;
+    unsigned m = 0;
+    const int tx = bx << 1, ty = by << 1;
+    const bool cx0 = tx >= x0 && tx < x1, cx1 = tx + 1 >= x0 && tx + 1 < x1;
+    if (ty >= y0 && ty < y1) { if (cx0) m |= 1u; if (cx1) m |= 2u; }
+    if (ty + 1 >= y0 && ty + 1 < y1) { if (cx0) m |= 4u; if (cx1) m |= 8u; }
+    return m;
+}
+
+// Every thread of the workgroup calls it.  store(slot, depth bits, id | mask << 28) is called once per record of
+// super-tile bucket `sb`, slots 0 .. hits - 1 in arbitrary order; returns the number of hits.
+//   pl   : LDS, pull_lds_words(pt.nrows) words
+//   cand : LDS, cand_cap words (a multiple of 64): the payload indices of one chunk of candidates
+// Window rows -> runs of the payload (two reads of the key starts per row), exclusive scan of the run lengths, then
+// the runs are spelled out as candidate indices in LDS so that the candidate loop has 64 busy lanes and all of a
+// thread's payload loads in flight together (a run is ~17 candidates long on average).
+template <int THREADS, typename F>
+__device__ __forceinline__ int pull_bucket(const uint4* __restrict__ sorted, const int32_t* __restrict__ cstart,
+                                           int64_t n_visible, const PullTab& pt, const Geo& g, int sb, unsigned* pl,
+                                           unsigned* cand, int cand_cap, F&& store) {
+    constexpr int WAVES = THREADS / 64, U = 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cam = sb / g.ST, srem = sb - cam * g.ST;
+    const int by = srem / g.stw, bx = srem - by * g.stw;
+    const int nrows = pt.nrows;
+    unsigned* seg_start = pl;
+    unsigned* seg_off = pl + nrows;               // [nrows + 1]
+    unsigned* hits = pl + 2 * nrows + 1;
+    const int smax = max(g.stw, g.sth);
+    for (int r = t; r < nrows; r += THREADS) {
+        int c = 0, r0 = 0;
+#pragma unroll
+        for (int k = 1; k < PULL_MAX_CLS; ++k)
+            if (k < g.ncls && r >= pt.row0[k]) { c = k; r0 = pt.row0[k]; }
+        const int dy = r - r0;
+        const int sz = c == g.ncls - 1 ? smax : pull_size(c);
+        const int y = by - dy;
+        unsigned st = 0, len = 0;
+        if (y >= 0 && dy < sz) {
+            const int rowkey = ((cam * g.ncls + c) * g.sth + y) * g.stw;
+            const int a = cstart[rowkey + max(bx - sz + 1, 0)], b = cstart[rowkey + bx + 1];
+            if (a >= 0 && b > a && (int64_t)b <= n_visible) { st = (unsigned)a; len = (unsigned)(b - a); }
+        }
+        seg_start[r] = st;
+        seg_off[r] = len;
+    }
+    if (t == 0) *hits = 0u;
+    __syncthreads();
+    if (wave == 0) {                               // exclusive scan of the run lengths
+        unsigned carry = 0;
+        for (int b0 = 0; b0 < nrows; b0 += 64) {
+            const int i = b0 + lane;
+            const unsigned v = i < nrows ? seg_off[i] : 0u;
+            const unsigned incl = (unsigned)sc_wave_incl_scan((int)v);
+            if (i < nrows) seg_off[i] = carry + incl - v;
+            carry += (unsigned)__shfl((int)incl, 63, 64);
+        }
+        if (lane == 0) seg_off[nrows] = carry;
+    }
+    __syncthreads();
+    const int total = (int)seg_off[nrows];
+    for (int c0 = 0; c0 < total; c0 += cand_cap) {
+        const int cn = min(cand_cap, total - c0);
+        for (int r = wave; r < nrows; r += WAVES) {           // runs round-robin over the waves, 64 candidates per step
+            const int off = (int)seg_off[r], end = (int)seg_off[r + 1];
+            const int lo = max(off, c0), hi = min(end, c0 + cn);
+            const unsigned st = seg_start[r];
+            for (int i = lo + lane; i < hi; i += 64) cand[i - c0] = st + (unsigned)(i - off);
+        }
+        __syncthreads();
+        for (int base = 0; base < cn; base += THREADS * U) {   // wave-uniform trip count (ballots inside)
+            uint4 pay[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * THREADS + t;
+                pay[u] = i < cn ? sorted[cand[i]] : make_uint4(0u, 0u, 0u, 0u);       // (0, 0, 0, 0): an empty rectangle
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned m = pull_tile_mask((int)(pay[u].x & 0xffffu), (int)(pay[u].x >> 16), (int)(pay[u].y & 0xffffu),
+                                                  (int)(pay[u].y >> 16), bx, by, g.ss);
+                const unsigned long long bal = __ballot(m != 0u);
+                if (bal) {
+                    unsigned b = 0;
+                    if (lane == 0) b = atomicAdd(hits, (unsigned)__popcll(bal));
+                    b = (unsigned)__shfl((int)b, 0, 64);
+                    if (m) store(b + (unsigned)__popcll(bal & sc_lanemask_lt()), pay[u].z, (pay[u].w & ID_MASK) | (m << 28));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    return (int)*hits;
+}
+
 // LDS of the sort: [B: cap u64][order: cap u16][boff: cap + 2 u32][coarse: NC u32][table][totals 4 u32]
 // (14 B per record + 2.6 KiB: three workgroups per CU up to cap = 3584)
 // (`threads` = the workgroup size of the instantiation: SS_THREADS, or SS_SMALL_THREADS for frames of small buckets)
@@ -862,12 +1058,16 @@ __host__ __device__ inline size_t sort_lds_bytes(int cap, int threads = SS_THREA
 //   counting sort into the n fine buckets, then every record is ranked inside its bucket by counting
 //   smaller keys.  Whatever the distribution the result is the exact order; only the cost of the ranking
 //   loop depends on it (equal depths are separated by the id bits of the key).
-template <int THREADS, int RPT>
+struct PullCtx { const uint4* sorted; const int32_t* cstart; int64_t n_visible; const PullTab* pt; };
+
+// PULL: the records are gathered from the spatially sorted payload (pull_bucket) instead of read from `recs`; `n` is then
+// the bucket's expected size (from the count phase) and only bounds the result.
+template <int THREADS, int RPT, bool PULL = false>
 __device__ __forceinline__ void sort_segment(
     const uint2* __restrict__ recs, int n, int sb, const int* tb, int cap, const Geo& g,
     const int32_t* __restrict__ offsets, int n_tbuckets, int64_t n_isects, int tile_bits,
-    unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out
-    SC_DIAG_PARAM(dbg)) {
+    unsigned char* smem, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids, unsigned* totals_out,
+    const PullCtx& pc SC_DIAG_PARAM(dbg)) {
     constexpr int WAVES = THREADS / 64, NC = THREADS;          // coarse bins: one per thread
     unsigned long long* B = reinterpret_cast<unsigned long long*>(smem);
     unsigned short* order = reinterpret_cast<unsigned short*>(B + cap);      // cap is a multiple of 256
@@ -880,16 +1080,35 @@ __device__ __forceinline__ void sort_segment(
     __shared__ unsigned red_sum[WAVES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
+    // the segment's records are read ONCE (from global memory, all loads of a thread in flight together; or gathered
+    // into B by the pull) and stay in registers through the min/max, both counting passes and the scatter
+    uint2 rec[RPT];
+    if (PULL) {
+        // the candidate indices and the run table live where order[] / boff[] will be (6 B per record, free until the sort)
+        const int pw = (int)pull_lds_words(pc.pt->nrows);
+        const int cand_cap = ((cap * 6) / 4 - pw) & ~63;        // >= 64: the host keeps cap >= 1024 on the pull route
+        unsigned* cand = reinterpret_cast<unsigned*>(order);
+        const int nh = pull_bucket<THREADS>(pc.sorted, pc.cstart, pc.n_visible, *pc.pt, g, sb, cand + cand_cap, cand, cand_cap,
+                                            [&](unsigned slot, unsigned depth, unsigned idw) {
+                                                if (slot < (unsigned)cap) B[slot] = ((unsigned long long)depth << 32) | idw;
+                                            });
+        n = min(min(nh, n), cap);         // (nh == n unless the inputs changed between the count and the sort phase)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = t + k * THREADS;
+            const unsigned long long v = (i < n) ? B[i] : 0ull;
+            rec[k] = make_uint2((unsigned)(v >> 32), (unsigned)v);
+        }
+        __syncthreads();                  // cand[] is dead, B is in registers
+    } else {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int i = t + k * THREADS;
+            rec[k] = (i < n) ? recs[i] : make_uint2(0u, 0u);
+        }
+    }
     for (int i = t; i <= n; i += THREADS) boff[i] = 0;
     coarse[t] = 0u;
-    // the segment's records are read from global memory ONCE, all loads of a thread in flight together,
-    // and stay in registers through the min/max, both counting passes and the scatter
-    uint2 rec[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int i = t + k * THREADS;
-        rec[k] = (i < n) ? recs[i] : make_uint2(0u, 0u);
-    }
     unsigned long long lo = ~0ull, hi = 0ull;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -1075,19 +1294,23 @@ __device__ __forceinline__ void sort_heavy_segment(
 // One launch sorts everything: blocks [0, seg_bound) take the segments big_split_kernel produced (none in the
 // common case: those blocks return at once), blocks [seg_bound, seg_bound + n_sbuckets) the super-tiles whose
 // bucket fits the LDS capacity.
-template <int THREADS, int RPT>
+template <int THREADS, int RPT, bool PULL>
 __global__ __launch_bounds__(THREADS, 6) void super_sort_kernel(
     const uint2* __restrict__ records, uint2* __restrict__ records_rw, const uint2* __restrict__ temp,
     const Segment* __restrict__ segs, const unsigned* __restrict__ n_segs, int seg_bound,
     const int32_t* __restrict__ soffsets, int n_sbuckets, int n_tbuckets,
     Geo g, const int32_t* __restrict__ offsets, const int64_t* __restrict__ meta, int64_t capacity,
     int64_t rec_capacity, int64_t super_capacity, int tile_bits, int cap,
-    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids SC_DIAG_PARAM(dbg)) {
+    int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
+    const uint4* __restrict__ sorted, const int32_t* __restrict__ cstart, const int64_t* __restrict__ n_visible,
+    PullTab pt SC_DIAG_PARAM(dbg)) {
     extern __shared__ __align__(16) unsigned char smem[];
     // the SAME three comparisons in every kernel of the sort phase and in the host wrapper
     // (rendering._bin_launch_ran): a launch either runs in full or not at all
     if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
     __shared__ int tb_s[4];
+    PullCtx pc;
+    pc.sorted = sorted; pc.cstart = cstart; pc.n_visible = PULL ? n_visible[0] : 0; pc.pt = &pt;
     if (THREADS == SS_THREADS && (int)blockIdx.x < seg_bound) {      // (the small form is launched without segments)
         if (blockIdx.x >= *n_segs) return;
         const Segment* sg = segs + blockIdx.x;
@@ -1098,19 +1321,48 @@ __global__ __launch_bounds__(THREADS, 6) void super_sort_kernel(
             sort_heavy_segment(temp + start, records_rw + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets,
                                meta[0], tile_bits, smem, isect_ids, flatten_ids);
         else
-            sort_segment<SS_THREADS, SS_RPT>(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem,
-                                             isect_ids, flatten_ids, nullptr SC_DIAG_ARG(dbg));
+            sort_segment<SS_THREADS, SS_RPT, false>(temp + start, sn, ssb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits,
+                                                    smem, isect_ids, flatten_ids, nullptr, pc SC_DIAG_ARG(dbg));
         return;
     }
-    const int sb = (int)blockIdx.x - seg_bound;
+    int sb = (int)blockIdx.x - seg_bound;
+    if (PULL) {
+        // neighbouring buckets gather overlapping windows of the payload: blocks go round-robin over the 8 XCDs, so XCD x
+        // takes the x-th eighth of the buckets (a band of super-tile rows) and its L2 holds that band's part of the payload
+        const int per = (n_sbuckets + 7) >> 3;
+        sb = (sb & 7) * per + (sb >> 3);
+        if (sb >= n_sbuckets) return;
+    }
     const int s = soffsets[sb];
     const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
     const int n = e - s;
     if (n <= 0 || n > cap) return;          // n > cap: big_split_kernel has cut this bucket into segments
     if (threadIdx.x < 4) tb_s[threadIdx.x] = 0;
     __syncthreads();
-    sort_segment<THREADS, RPT>(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
-                               flatten_ids, nullptr SC_DIAG_ARG(dbg));
+    sort_segment<THREADS, RPT, PULL>(records + s, n, sb, tb_s, cap, g, offsets, n_tbuckets, meta[0], tile_bits, smem, isect_ids,
+                                     flatten_ids, nullptr, pc SC_DIAG_ARG(dbg));
+}
+
+// PULL route, oversized buckets (n > cap): their records are gathered into the records buffer -- the slice the scatter
+// route would have filled -- and big_split_kernel then cuts them into segments as before.  One workgroup per bucket.
+constexpr int BP_THREADS = 1024;
+constexpr int BP_CAND = 8192;                     // candidate indices per chunk (32 KB of LDS)
+__global__ __launch_bounds__(BP_THREADS) void big_pull_kernel(
+    const uint4* __restrict__ sorted, const int32_t* __restrict__ cstart, const int64_t* __restrict__ n_visible, PullTab pt,
+    Geo g, const int32_t* __restrict__ soffsets, int n_sbuckets, const int64_t* __restrict__ meta, int64_t capacity,
+    int64_t rec_capacity, int64_t super_capacity, int cap, uint2* __restrict__ records) {
+    extern __shared__ unsigned lds[];
+    if (meta[0] > capacity || meta[2] > rec_capacity || meta[3] > super_capacity) return;
+    const int sb = (int)blockIdx.x;
+    const int s = soffsets[sb];
+    const int e = (sb + 1 < n_sbuckets) ? soffsets[sb + 1] : (int)meta[2];
+    const int n = e - s;
+    if (n <= cap || (int64_t)e > rec_capacity) return;
+    uint2* dst = records + s;
+    pull_bucket<BP_THREADS>(sorted, cstart, n_visible[0], pt, g, sb, lds + BP_CAND, lds, BP_CAND,
+                            [&](unsigned slot, unsigned depth, unsigned idw) {
+                                if (slot < (unsigned)n) dst[slot] = make_uint2(depth, idw);
+                            });
 }
 
 // ---- isect_ids on demand ------------------------------------------------------------------------------------
@@ -1341,9 +1593,36 @@ __global__ __launch_bounds__(BS_THREADS, 8) void big_split_kernel(
 struct BinLayout {
     Geo g;
     int C, nt_cells, ns_cells, nsb, ntb;
+    int nkeys;                 // pull route: (camera, size class, anchor) keys; 0 on the scatter route
+    PullTab pt;
     size_t dgrid_t, dgrid_s, chist, ccursor, rcursor, nseg, scans_done, wstat, soffsets, cstart, smeta, cmeta, whint, sorted, total;
 };
 
+int g_sc_isect_pull = 0;       // sc_set_option "isect_pull": 1 = the pull route where the frame allows it, 0 (default) = the scatter route
+
+// The pull route's size classes for a grid of stw x sth super-tiles (0 = the frame takes the scatter route: the key
+// starts of a centre workgroup (4 B per key) and the window-row table must fit the LDS).
+static int pull_classes(int C, int stw, int sth, PullTab* pt) {
+    if (!g_sc_isect_pull) return 0;
+    const int smax = stw > sth ? stw : sth;
+    int n = 1;
+    while (n < PULL_MAX_CLS && pull_size(n - 1) < smax) ++n;
+    if ((size_t)C * n * stw * sth * 4 > 140 * 1024) return 0;
+    int rows = 0;
+    for (int c = 0; c < PULL_MAX_CLS + 1; ++c) pt->row0[c] = 0;
+    for (int c = 0; c < n; ++c) {
+        pt->row0[c] = rows;
+        const int sz = c == n - 1 ? smax : pull_size(c);
+        rows += sz < sth ? sz : sth;
+    }
+    for (int c = n; c <= PULL_MAX_CLS; ++c) pt->row0[c] = rows;
+    pt->nrows = rows;
+    if (rows > 1024) return 0;
+    return n;
+}
+
+// (`pull`: -1 = as sc_set_option "isect_pull" and the frame's size decide; the layout is the same either way -- the
+//  histogram / cursor arrays are sized for the larger of the two routes -- so that both calls of a frame agree on it)
 static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_height) {
     BinLayout L;
     L.C = C;
@@ -1355,18 +1634,28 @@ static BinLayout bin_layout(int64_t CN, int C, int N, int tile_width, int tile_h
     L.nsb = C * L.g.ST;
     L.nt_cells = C * (tile_height + 1) * (tile_width + 1);
     L.ns_cells = C * (L.g.sth + 1) * (L.g.stw + 1);
+    // the workspace is laid out for the pull route's key count whether or not the option is on (sizes must not depend on a
+    // switch that can change between sc_isect_bin_workspace_bytes and the launch)
+    PullTab tmp;
+    const int keep = g_sc_isect_pull;
+    g_sc_isect_pull = 1;
+    const int ncls_max = pull_classes(C, L.g.stw, L.g.sth, &tmp);
+    g_sc_isect_pull = keep;
+    L.g.ncls = pull_classes(C, L.g.stw, L.g.sth, &L.pt);
+    L.nkeys = L.g.ncls * L.nsb;
+    const size_t nk = (size_t)(ncls_max > 0 ? ncls_max : 1) * L.nsb + 2;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += sc_align_up(bytes, 256); return at; };
     L.dgrid_t = take((size_t)L.nt_cells * 4);
     L.dgrid_s = take((size_t)L.ns_cells * 4);
-    L.chist = take((size_t)L.nsb * 4);
-    L.ccursor = take((size_t)L.nsb * 4);
+    L.chist = take(nk * 4);
+    L.ccursor = take(nk * 4);
     L.rcursor = take((size_t)L.nsb * 4);
     L.nseg = take(4);
     L.scans_done = take(4);
     L.wstat = take(16);                                   // maximum and sum of the rasterizer's work hints (zeroed per frame)
     L.soffsets = take((size_t)L.nsb * 4);
-    L.cstart = take((size_t)L.nsb * 4);
+    L.cstart = take(nk * 4);                              // pull route: the key starts (nkeys + 1)
     L.smeta = take(16);
     L.cmeta = take(16);
     L.whint = take((size_t)L.ntb * 4);                    // the per-tile hints the order job files the tiles under
@@ -1395,7 +1684,9 @@ static hipError_t bin_attrs_once() {
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS, 64>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)bin_scatter_flat_kernel<FLAT_THREADS_SMALL, 16>, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)center_scatter_kernel, (hipFuncAttribute)a, 152 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel<SS_THREADS, SS_RPT>, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel<SS_THREADS, SS_RPT, false>, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)super_sort_kernel<SS_THREADS, SS_RPT, true>, (hipFuncAttribute)a, 100 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)big_pull_kernel, (hipFuncAttribute)a, 64 * 1024)) != hipSuccess) return e;
     done[dev] = true;
     return hipSuccess;
 }
@@ -1406,7 +1697,8 @@ static inline size_t seg_bound_for(int64_t n_records, int nsb) {
 }
 
 static inline size_t count_lds_bytes(const BinLayout& L) {
-    return (size_t)(L.nt_cells + L.ns_cells + L.nsb) * 4;
+    // (pull route: the key histogram as 16-bit halves)
+    return (size_t)(L.nt_cells + L.ns_cells + (L.g.ncls ? (L.nkeys + 1) / 2 : L.nsb)) * 4;
 }
 
 extern "C" size_t sc_isect_bin_workspace_bytes(int64_t CN, int C, int tile_width, int tile_height,
@@ -1507,6 +1799,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     jobs.j[2] = jobs.j[1];
     unsigned* scans_done = (unsigned*)(ws + L.scans_done);
     size_t center_lds = (size_t)L.nsb * 12 > (size_t)L.nt_cells * 4 ? (size_t)L.nsb * 12 : (size_t)L.nt_cells * 4;
+    if ((size_t)L.nkeys * 4 + 16 > center_lds) center_lds = (size_t)L.nkeys * 4 + 16;     // pull route: the key starts
     // the order job: 1024 class counters + a class per tile (2 B) + room to stage the forward list (2 B per item)
     const size_t n_fwd_items = (size_t)L.ntb + L.ntb / 8 + 8;
     const size_t order_lds_staged = 4096 + ((size_t)L.ntb + 2) * 2 + n_fwd_items * 2 + 16;
@@ -1515,7 +1808,7 @@ extern "C" int sc_isect_bin_count(const float* means2d, const int32_t* radii, co
     if (tile_order && center_lds < order_lds) center_lds = order_lds;
     hipLaunchKernelGGL(center_scatter_kernel, dim3(grid + 3), dim3(BIN_THREADS), center_lds, s,
                        (const int32_t*)tiles_per_gauss, means2d, radii, CN, L.g, (float)tile_size, L.nsb,
-                       depths, (const unsigned*)chist, ccursor, sorted, cmeta, jobs, scans_done, meta_dev,
+                       depths, (const unsigned*)chist, ccursor, sorted, cmeta, (int32_t*)(ws + L.cstart), jobs, scans_done, meta_dev,
                        meta_mirror, seq, (const unsigned*)whint, (const unsigned*)wstat, tile_order, L.ntb, staged,
                        g_sc_raster_split, g_sc_raster_bwd_split ? 0 : 1 SC_DIAG_ARG(g_sc_debug[1] >> 16));
     SC_LAUNCH_CHECK();
@@ -1588,12 +1881,24 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
     uint2* temp = (uint2*)((unsigned char*)workspace + rec_bytes);
     Segment* segs = (Segment*)((unsigned char*)workspace + 2 * rec_bytes);
     const int seg_bound = big ? (int)seg_bound_for(rec_capacity, L.nsb) : 0;
+    const bool pull = L.g.ncls > 0;
+    if (pull && cap < SS_SMALL_CAP) cap = SS_SMALL_CAP;      // (the gather's candidate table lives in 6 B x cap of the sort's LDS)
+    const int32_t* cstart = (const int32_t*)(cws + L.cstart);
     // 64 Gaussians per wave, 512 per workgroup -- unless the set is a few (<= 262 144) HUGE splats (a sky: more than 32
     // records per Gaussian, walked rectangle by rectangle by whole waves) or tiny: then 16 per wave, so that every SIMD gets
     // a wave.  (Round 2 chose by the Gaussian count alone: S-100k, 9 records per Gaussian, took the sky's variant and
     // 2360 workgroups of fixed table work, 23 us.)
     const bool few_huge = CN <= 262144 && (rec_capacity > 32 * CN || CN < 32768);
-    if (!few_huge)
+    if (pull) {
+        // PULL route: no scatter launch and no records buffer -- every bucket's sort workgroup gathers its own records;
+        // only oversized buckets (when provisioned for) are gathered into their slice of `records` for big_split_kernel
+        if (big) {
+            SC_HIP(bin_attrs_once());
+            hipLaunchKernelGGL(big_pull_kernel, dim3((unsigned)L.nsb), dim3(BP_THREADS),
+                               (BP_CAND + pull_lds_words(L.pt.nrows)) * 4, s, sorted, cstart, cmeta, L.pt, L.g, soffsets, L.nsb,
+                               meta_dev, capacity, rec_capacity, super_capacity, cap, records);
+        }
+    } else if (!few_huge)
         hipLaunchKernelGGL((bin_scatter_flat_kernel<FLAT_THREADS, 64>), dim3((unsigned)((CN + FLAT_THREADS - 1) / FLAT_THREADS)),
                            dim3(FLAT_THREADS), (size_t)L.nsb * 8 + 16 + (FLAT_THREADS / 64) * sizeof(FlatTab), s, sorted, cmeta,
                            L.g, L.nsb, soffsets, meta_dev, capacity, rec_capacity, super_capacity, cursor, records
@@ -1614,17 +1919,20 @@ extern "C" int sc_isect_bin_sort(const float* means2d, const int32_t* radii, con
                            n_segs, seg_bound, soffsets, L.nsb, meta_dev, capacity, rec_capacity, super_capacity, cap SC_DIAG_ARG(g_sc_debug[3]));
         SC_LAUNCH_CHECK();
     }
-    if (!big && cap <= SS_SMALL_CAP)
-        hipLaunchKernelGGL((super_sort_kernel<SS_SMALL_THREADS, SS_SMALL_RPT>), dim3((unsigned)L.nsb), dim3(SS_SMALL_THREADS),
-                           sort_lds_bytes(cap, SS_SMALL_THREADS), s,
-                           (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
-                           (const unsigned*)n_segs, 0, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
-                           capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
-    else
-        hipLaunchKernelGGL((super_sort_kernel<SS_THREADS, SS_RPT>), dim3((unsigned)(seg_bound + L.nsb)), dim3(SS_THREADS), sort_lds_bytes(cap), s,
-                           (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs,
-                           (const unsigned*)n_segs, seg_bound, soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev,
-                           capacity, rec_capacity, super_capacity, tile_bits, cap, isect_ids, flatten_ids SC_DIAG_ARG(g_sc_debug[2]));
+    const unsigned nsb8 = (unsigned)((L.nsb + 7) / 8 * 8);     // (pull: the XCD-banded bucket map needs whole rounds of 8 blocks)
+#define SC_LAUNCH_SORT(THREADSP, RPTP, PULLP, GRID, LDSB, SEGB)                                                               \
+    hipLaunchKernelGGL((super_sort_kernel<THREADSP, RPTP, PULLP>), dim3(GRID), dim3(THREADSP), LDSB, s,                       \
+                       (const uint2*)records, records, (const uint2*)temp, (const Segment*)segs, (const unsigned*)n_segs, SEGB, \
+                       soffsets, L.nsb, L.ntb, L.g, isect_offsets, meta_dev, capacity, rec_capacity, super_capacity, tile_bits,  \
+                       cap, isect_ids, flatten_ids, sorted, cstart, cmeta, L.pt SC_DIAG_ARG(g_sc_debug[2]))
+    if (!big && cap <= SS_SMALL_CAP) {
+        if (pull) SC_LAUNCH_SORT(SS_SMALL_THREADS, SS_SMALL_RPT, true, nsb8, sort_lds_bytes(cap, SS_SMALL_THREADS), 0);
+        else SC_LAUNCH_SORT(SS_SMALL_THREADS, SS_SMALL_RPT, false, (unsigned)L.nsb, sort_lds_bytes(cap, SS_SMALL_THREADS), 0);
+    } else {
+        if (pull) SC_LAUNCH_SORT(SS_THREADS, SS_RPT, true, (unsigned)seg_bound + nsb8, sort_lds_bytes(cap), seg_bound);
+        else SC_LAUNCH_SORT(SS_THREADS, SS_RPT, false, (unsigned)(seg_bound + L.nsb), sort_lds_bytes(cap), seg_bound);
+    }
+#undef SC_LAUNCH_SORT
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

@@ -65,6 +65,7 @@ extern "C" int sc_tile_order_len(int total_tiles);      // raster_fwd.hip
 constexpr int SC_VIEW_SLOTS = 8;
 constexpr int SC_VIEW_REGISTRY_WORDS = 4 + 4 * SC_VIEW_SLOTS;   // [0] call counter; per slot: forward axis (3 floats), stamp
 __host__ __device__ static inline int sc_clamp_view_slot(int v) { return v < 0 ? 0 : (v >= SC_VIEW_SLOTS ? SC_VIEW_SLOTS - 1 : v); }
+extern int g_sc_isect_pull;          // sc_set_option "isect_pull" (isect_bin.hip)
 extern int g_sc_raster_bwd_split;    // sc_set_option "raster_bwd_split" (raster_bwd.hip)
 extern int g_sc_raster_hint_blend;   // sc_set_option "raster_hint_blend"
 extern int g_sc_raster_split;   // sc_set_option "raster_split" (raster_fwd.hip; read by the order job of isect_bin.hip)
