@@ -263,6 +263,19 @@ int sc_rasterize_fwd_packed(const float* records, const float* backgrounds, cons
                             const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
                             float* render_colors, float* render_alphas, const int32_t* tile_order,
                             int32_t* tile_work, int depth_normalise, sc_stream_t stream);
+/* sc_rasterize_fwd with render_colors stored as PLANES, [C][D][H][W] (one plane per channel), for inference (no
+ * last_ids).  The reference's caller slices the result channel-wise right behind the operator
+ * (street_gaussian_renderer.py:282-300: `render_colors[..., :-1]`, `[..., -1:] / alpha`, clamp, `.permute(2, 0, 1)`):
+ * strided kernels over the interleaved buffer, dense ones over planes.  The Python operator hands the buffer out as a
+ * permuted [C,H,W,D] view, so the values a caller sees are identical.  Wave kernel only (tile_size 16, D = 3 or 4):
+ * SC_EUNSUPPORTED otherwise. */
+int sc_rasterize_fwd_planar(const float* means2d, const float* conics, const float* colors,
+                            const float* opacities, const float* backgrounds, const uint8_t* tile_masks,
+                            int C, int N, int D, int width, int height, int tile_size,
+                            int tile_width, int tile_height,
+                            const int32_t* isect_offsets, const int32_t* flatten_ids, int64_t n_isects,
+                            float* render_colors, float* render_alphas,
+                            const int32_t* tile_order, int32_t* tile_work, sc_stream_t stream);
 /* conics [CN,3] / opacities [CN] / colors4 [CN,4] (each nullable) out of CN records */
 int sc_records_unpack(const float* records, int64_t CN, float* conics, float* opacities, float* colors4,
                       sc_stream_t stream);
@@ -285,13 +298,35 @@ int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* 
  * Each product / sum is rounded separately: bit-identical to the reference's torch composition. */
 int sc_frame_composite_u8(const float* fg, int fg_stride, const float* acc, const float* sky, int sky_stride,
                           int64_t n_pixels, int rounding, uint8_t* out, sc_stream_t stream);
+/* The same for images with a channel stride: channel c of pixel i at fg[i * fg_pix_stride + c * fg_ch_stride] -- the
+ * planes sc_rasterize_fwd_planar writes have pixel stride 1 and channel stride H * W. */
+int sc_frame_composite_u8_strided(const float* fg, int64_t fg_pix_stride, int64_t fg_ch_stride, const float* acc,
+                                  const float* sky, int64_t sky_pix_stride, int64_t sky_ch_stride, int64_t n_pixels,
+                                  int rounding, uint8_t* out, sc_stream_t stream);
 
 /* unit-test hook for the backward kernel's transposing reduction (v_permlane32/16_swap + DPP):
  * in [n_waves][16][64] per-lane partial sums, out [n_waves][64]: lane l = 64-lane total of value l >> 2 */
 int sc_test_wave_transpose_sum16(const float* in, int n_waves, float* out, sc_stream_t stream);
 
+/* ---- HIP streams with a CU mask or a priority (frame loop: street_crafter_amd/dist.py, bench.py) ----------------
+ * Frames are independent (render.py:64-70) and several are kept in flight on different streams; the VALU-bound
+ * rasterizer (10.7 k one-wave workgroups) otherwise starves the 8..16-wave workgroups of the NEXT frame's latency-bound
+ * intersection kernels of CU slots.  sc_stream_create makes a non-blocking stream that is either confined to a set of
+ * CUs (n_mask_words > 0: hipExtStreamCreateWithCUMask; bit i of the mask = CU i, the driver deals the bits round-robin
+ * over the 8 XCDs, so "the first K bits" is K / 8 CUs of every XCD) or has a priority (n_mask_words == 0:
+ * hipStreamCreateWithPriority; the range is returned by sc_stream_priority_range, lower number = higher priority).
+ * The handle is a hipStream_t; the caller destroys it with sc_stream_destroy after synchronising it. */
+int sc_stream_create(int priority, const uint32_t* cu_mask, int n_mask_words, sc_stream_t* out);
+int sc_stream_destroy(sc_stream_t stream);
+int sc_stream_priority_range(int* least, int* greatest);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
+ *   key "isect_pull": 1 = sc_isect_bin_count / _sort take the PULL route (every super-tile bucket's sort workgroup
+ *                     gathers its own records from a (size class, anchor)-sorted payload: no scatter launch, no records
+ *                     buffer) for frames whose key table fits the LDS; 0 = the scatter route (default; the pull route
+ *                     measured slower, profiles/r04_isect_pull_ab.txt).  Same results bit for bit.  Set it between
+ *                     frames (both calls of a frame must see the same value).
  *   key "raster_fwd": 0 = reference-shaped (all pixels x all splats; generic fallback / cross-check),
  *                     3 = one wave per tile, 4 pixels per lane, exact tile-level cull (default)
  *   key "raster_map": block -> tile map of the wave rasterizer: 1 = neighbouring tiles round-robin over the

@@ -82,6 +82,9 @@ SIGNATURES = {
     "sc_rasterize_fwd_ed": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
                                       c_f32p, c_f32p, c_i32p, c_i32p, c_stream]),
+    "sc_rasterize_fwd_planar": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_int64,
+                                          c_f32p, c_f32p, c_i32p, c_i32p, c_stream]),
     "sc_camera_centers": (C.c_int, [c_f32p, C.c_int, c_f32p, c_stream]),
     "sc_projection_sh_fwd": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -99,7 +102,12 @@ SIGNATURES = {
     "sc_knn3_mean_dist2": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "sc_frame_composite_u8": (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int64, C.c_int, c_u8p,
                                         c_stream]),
+    "sc_frame_composite_u8_strided": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64,
+                                                C.c_int, c_u8p, c_stream]),
     "sc_test_wave_transpose_sum16": (C.c_int, [c_f32p, C.c_int, c_f32p, c_stream]),
+    "sc_stream_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "sc_stream_destroy": (C.c_int, [c_stream]),
+    "sc_stream_priority_range": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sc_set_option": (C.c_int, [C.c_char_p, C.c_int]),
 }
 

@@ -207,6 +207,26 @@ RasterFwdT rasterize_fwd_c(const Tensor& means2d, const Tensor& conics, const Te
                                     S(stream));
     return {rc, rc_, ra, last};
 }
+// render_colors as planes [C][D][H][W], handed out as the permuted [C,H,W,D] view (sc_rasterize_fwd_planar; inference only).
+// rc == SC_EUNSUPPORTED: nothing was launched, the caller takes rasterize_fwd.
+py::tuple rasterize_fwd_planar(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
+                               const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
+                               const Tensor& offsets, const Tensor& flatten_ids, const OptT& order, const OptT& work,
+                               int64_t stream) {
+    req(means2d, at::kFloat, "means2d"); req(conics, at::kFloat, "conics"); req(colors, at::kFloat, "colors");
+    req(opacities, at::kFloat, "opacities"); req(offsets, at::kInt, "isect_offsets"); req(flatten_ids, at::kInt, "flatten_ids");
+    const int64_t C = opacities.size(0), N = opacities.size(1), D = colors.size(-1);
+    const int64_t th = offsets.size(1), tw = offsets.size(2);
+    Tensor planes = at::empty({C, D, height, width}, f32(means2d));
+    Tensor ra = at::empty({C, height, width, 1}, f32(means2d));
+    const int rc = sc_rasterize_fwd_planar(fp(means2d), fp(conics), fp(colors), fp(opacities), fpo(backgrounds),
+                                           masks ? static_cast<const uint8_t*>(masks->data_ptr()) : nullptr, (int)C, (int)N,
+                                           (int)D, (int)width, (int)height, (int)tile_size, (int)tw, (int)th, ip(offsets),
+                                           ip(flatten_ids), flatten_ids.numel(), fpw(planes), fpw(ra),
+                                           order ? ip(*order) : nullptr,
+                                           work ? static_cast<int32_t*>(work->data_ptr()) : nullptr, S(stream));
+    return py::make_tuple(rc, planes.permute({0, 2, 3, 1}), ra);
+}
 py::tuple rasterize_fwd(const Tensor& means2d, const Tensor& conics, const Tensor& colors, const Tensor& opacities,
                         const OptT& backgrounds, const OptT& masks, int64_t width, int64_t height, int64_t tile_size,
                         const Tensor& offsets, const Tensor& flatten_ids, bool want_last, const OptT& order,
@@ -464,6 +484,13 @@ py::tuple rasterize_autograd(const Tensor& means2d, const Tensor& conics, const 
 }
 
 // ---- frame export ---------------------------------------------------------------------------------------------
+int frame_composite_u8_strided(int64_t fg_ptr, int64_t fg_pix, int64_t fg_ch, int64_t acc_ptr, int64_t sky_ptr, int64_t sky_pix,
+                               int64_t sky_ch, int64_t n_pixels, int64_t rounding, const Tensor& out, int64_t stream) {
+    return sc_frame_composite_u8_strided(reinterpret_cast<const float*>(static_cast<uintptr_t>(fg_ptr)), fg_pix, fg_ch,
+                                         reinterpret_cast<const float*>(static_cast<uintptr_t>(acc_ptr)),
+                                         reinterpret_cast<const float*>(static_cast<uintptr_t>(sky_ptr)), sky_pix, sky_ch,
+                                         n_pixels, (int)rounding, static_cast<uint8_t*>(out.data_ptr()), S(stream));
+}
 int frame_composite_u8(int64_t fg_ptr, int64_t fg_stride, int64_t acc_ptr, int64_t sky_ptr, int64_t sky_stride,
                        int64_t n_pixels, int64_t rounding, const Tensor& out, int64_t stream) {
     return sc_frame_composite_u8(reinterpret_cast<const float*>(static_cast<uintptr_t>(fg_ptr)), (int)fg_stride,
@@ -485,6 +512,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("sh_fwd", &sh_fwd);
     m.def("sh_bwd", &sh_bwd);
     m.def("rasterize_fwd", &rasterize_fwd);
+    m.def("rasterize_fwd_planar", &rasterize_fwd_planar);
     m.def("rasterize_bwd", &rasterize_bwd);
     m.def("projection_autograd", &projection_autograd);
     m.def("sh_autograd", &sh_autograd);
@@ -492,4 +520,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("projection_sh_fwd", &projection_sh_fwd);
     m.def("rasterize_fwd_packed", &rasterize_fwd_packed);
     m.def("frame_composite_u8", &frame_composite_u8);
+    m.def("frame_composite_u8_strided", &frame_composite_u8_strided);
 }

@@ -48,6 +48,33 @@ extern "C" int sc_wait_i64(const int64_t* addr, int64_t value, int64_t timeout_u
     }
 }
 
+extern "C" int sc_stream_create(int priority, const uint32_t* cu_mask, int n_mask_words, sc_stream_t* out) {
+    if (!out || n_mask_words < 0 || (n_mask_words > 0 && !cu_mask)) return SC_EINVAL;
+    hipStream_t s = nullptr;
+    if (n_mask_words > 0) {
+        bool any = false;
+        for (int i = 0; i < n_mask_words; ++i) any = any || cu_mask[i] != 0u;
+        if (!any) return SC_EINVAL;                      // an empty mask would hang the first launch
+        SC_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_mask_words, cu_mask));
+    } else {
+        SC_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+    }
+    *out = (sc_stream_t)s;
+    return SC_OK;
+}
+
+extern "C" int sc_stream_destroy(sc_stream_t stream) {
+    if (!stream) return SC_EINVAL;
+    SC_HIP(hipStreamDestroy(sc_s(stream)));
+    return SC_OK;
+}
+
+extern "C" int sc_stream_priority_range(int* least, int* greatest) {
+    if (!least || !greatest) return SC_EINVAL;
+    SC_HIP(hipDeviceGetStreamPriorityRange(least, greatest));
+    return SC_OK;
+}
+
 extern "C" int sc_set_option(const char* key, int value) {
     if (!key) return SC_EINVAL;
 #ifdef SC_DIAG     // "debug0".."debug3" exist in the diagnostic build only: the shipped library answers SC_EINVAL
@@ -115,8 +142,9 @@ extern "C" int sc_set_option(const char* key, int value) {
 // the torch composition the reference spells out.
 namespace {
 __global__ __launch_bounds__(256) void frame_composite_u8_kernel(
-    const float* __restrict__ fg, int fg_stride, const float* __restrict__ acc,
-    const float* __restrict__ sky, int sky_stride, int64_t n_pix, int rounding, uint8_t* __restrict__ dst) {
+    const float* __restrict__ fg, int64_t fg_stride, int64_t fg_ch, const float* __restrict__ acc,
+    const float* __restrict__ sky, int64_t sky_stride, int64_t sky_ch, int64_t n_pix, int rounding,
+    uint8_t* __restrict__ dst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pix) return;
     const float* p = fg + i * fg_stride;
@@ -125,9 +153,9 @@ __global__ __launch_bounds__(256) void frame_composite_u8_kernel(
     const float bias = rounding ? 0.5f : 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float v = fminf(fmaxf(p[c], 0.0f), 1.0f);
+        float v = fminf(fmaxf(p[c * fg_ch], 0.0f), 1.0f);
         if (sky) {
-            const float s = fminf(fmaxf(q[c], 0.0f), 1.0f);
+            const float s = fminf(fmaxf(q[c * sky_ch], 0.0f), 1.0f);
             v = fminf(fmaxf(__fadd_rn(v, __fmul_rn(s, keep)), 0.0f), 1.0f);
         }
         dst[i * 3 + c] = (uint8_t)__fadd_rn(__fmul_rn(v, 255.0f), bias);
@@ -143,7 +171,24 @@ extern "C" int sc_frame_composite_u8(const float* fg, int fg_stride, const float
     if (n_pixels == 0) return SC_OK;
     if (!fg || !out) return SC_EINVAL;
     hipLaunchKernelGGL(frame_composite_u8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
-                       sc_s(stream), fg, fg_stride, acc, sky, sky_stride, n_pixels, rounding, out);
+                       sc_s(stream), fg, (int64_t)fg_stride, (int64_t)1, acc, sky, (int64_t)sky_stride, (int64_t)1, n_pixels,
+                       rounding, out);
+    SC_LAUNCH_CHECK();
+    return SC_OK;
+}
+
+// The same with a channel stride: images stored as planes (sc_rasterize_fwd_planar: pixel stride 1, channel stride H * W).
+extern "C" int sc_frame_composite_u8_strided(const float* fg, int64_t fg_pix_stride, int64_t fg_ch_stride, const float* acc,
+                                             const float* sky, int64_t sky_pix_stride, int64_t sky_ch_stride,
+                                             int64_t n_pixels, int rounding, uint8_t* out, sc_stream_t stream) {
+    if (n_pixels < 0 || fg_pix_stride < 1 || fg_ch_stride < 1 || (rounding != 0 && rounding != 1)) return SC_EINVAL;
+    if (sky && (sky_pix_stride < 1 || sky_ch_stride < 1)) return SC_EINVAL;
+    if ((sky != nullptr) != (acc != nullptr)) return SC_EINVAL;
+    if (n_pixels == 0) return SC_OK;
+    if (!fg || !out) return SC_EINVAL;
+    hipLaunchKernelGGL(frame_composite_u8_kernel, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0,
+                       sc_s(stream), fg, fg_pix_stride, fg_ch_stride, acc, sky, sky_pix_stride, sky_ch_stride, n_pixels,
+                       rounding, out);
     SC_LAUNCH_CHECK();
     return SC_OK;
 }

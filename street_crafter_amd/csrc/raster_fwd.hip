@@ -179,7 +179,12 @@ extern "C" int sc_diag_phase_cycles(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int CDIM, bool TRACK, int NSUB, bool PACKED = false, bool ED = false>
+// PLANAR: render_colors is stored [C][CDIM][H][W] (one plane per channel; the caller hands it out as a permuted [C,H,W,CDIM]
+// view) instead of interleaved [C][H][W][CDIM]: the reference caller's glue behind the operator (renderer.py:282-300) slices the
+// result channel-wise -- `render_colors[..., :-1]`, `[..., -1:] / alpha`, clamp, `.permute(2, 0, 1)` -- which are strided
+// kernels over the interleaved buffer and dense ones over planes (16.0 -> 11.0 and 14.6 -> 10.1 us at 1920x1280,
+// tools/exp_glue_layout.py).  A lane owns 4 (or 2) consecutive pixels of a row: one 16-B (8-B) store per channel.
+template <int CDIM, bool TRACK, int NSUB, bool PACKED = false, bool ED = false, bool PLANAR = false>
 __device__ __forceinline__ void raster_item(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -221,13 +226,16 @@ __device__ __forceinline__ void raster_item(
     }
     const int64_t pix0 = ((int64_t)cam * height + py_i) * width + px0_i;
 
+    // (PLANAR) first pixel of this lane in channel plane 0 of its camera; plane stride = height * width
+    const int64_t plane = (int64_t)height * width;
+    const int64_t ppix0 = (int64_t)cam * CDIM * plane + (int64_t)py_i * width + px0_i;
     if (tile_masks && !tile_masks[tflat]) {
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
             if (inside[k]) {
 #pragma unroll
                 for (int d = 0; d < CDIM; ++d)
-                    render_colors[(pix0 + k) * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
+                    render_colors[PLANAR ? ppix0 + d * plane + k : (pix0 + k) * CDIM + d] = backgrounds ? backgrounds[cam * CDIM + d] : 0.f;
                 render_alphas[pix0 + k] = 0.f;
                 if (last_ids) last_ids[pix0 + k] = 0;
             }
@@ -431,6 +439,34 @@ __device__ __forceinline__ void raster_item(
             pc_stage += pc2 - pc1; pc_issue += pc1 - pcw; pc_blend += pc3 - pc2; pc_batches += 1; pc_splats += (unsigned long long)bsz;
         }
     }
+    if (PLANAR) {
+        float Tv[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) Tv[k] = (k & 1) ? T2[k >> 1].y : T2[k >> 1].x;
+        // (inside[] is monotone along the lane's pixels: the last one inside means all are)
+        const bool v4 = PPL == 4 && (width & 3) == 0 && inside[PPL - 1];
+        const bool v2 = PPL >= 2 && (width & 1) == 0;
+        auto put = [&](float* base, const float* v) {
+            if (PPL == 4 && v4) { *reinterpret_cast<float4*>(base) = make_float4(v[0], v[1], v[2], v[3 < PPL ? 3 : 0]); return; }
+#pragma unroll
+            for (int j = 0; j + 1 < PPL; j += 2) {
+                if (v2 && inside[j + 1]) *reinterpret_cast<float2*>(base + j) = make_float2(v[j], v[j + 1]);
+                else { if (inside[j]) base[j] = v[j]; if (inside[j + 1]) base[j + 1] = v[j + 1]; }
+            }
+            if (PPL == 1 && inside[0]) base[0] = v[0];
+        };
+        float al[PPL];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) al[k] = 1.0f - Tv[k];
+        put(render_alphas + pix0, al);
+#pragma unroll
+        for (int d = 0; d < CDIM; ++d) {
+            float v[PPL];
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) v[k] = backgrounds ? acc[k][d] + Tv[k] * backgrounds[cam * CDIM + d] : acc[k][d];
+            put(render_colors + ppix0 + d * plane, v);
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         if (!inside[k]) continue;
@@ -467,7 +503,7 @@ __device__ __forceinline__ void raster_item(
 #endif
 }
 
-template <int CDIM, bool TRACK, bool PACKED = false, bool ED = false>
+template <int CDIM, bool TRACK, bool PACKED = false, bool ED = false, bool PLANAR = false>
 __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
     const float* __restrict__ means2d, const float* __restrict__ conics,
     const float* __restrict__ colors, const float* __restrict__ opacities,
@@ -511,12 +547,12 @@ __global__ __launch_bounds__(64) void raster_fwd_wave_kernel(
         }
     }
     if (kind == 0)
-        raster_item<CDIM, TRACK, 1, PACKED, ED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 1, PACKED, ED, PLANAR>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
                                     render_colors, render_alphas, last_ids, tflat, 0, xyoa_s, bck_s, col_s, tile_work
                                     SC_DIAG_ARG(dbg));
     else
-        raster_item<CDIM, TRACK, 2, PACKED, ED>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
+        raster_item<CDIM, TRACK, 2, PACKED, ED, PLANAR>(means2d, conics, colors, opacities, backgrounds, tile_masks, N, width, height,
                                     tile_width, tile_height, total_tiles, isect_offsets, flatten_ids, n_isects,
                                     render_colors, render_alphas, last_ids, tflat, kind - 1, xyoa_s, bck_s, col_s,
                                     tile_work SC_DIAG_ARG(dbg));
@@ -560,20 +596,24 @@ static int rasterize_fwd_impl(const float* means2d, const float* conics, const f
     const int NS = C * N;                 // kernels bound-check flatten ids against C*N
     const int variant = g_sc_raster_fwd_variant;
     // the depth-normalising epilogue exists in the wave-per-tile kernel with 4 channels only
-    if (epilogue && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
+    if ((epilogue & 3) && !(variant >= 3 && tile_size == 16 && D == 4)) return SC_EUNSUPPORTED;
+    if ((epilogue & 4) && !(variant >= 3 && tile_size == 16 && (D == 3 || D == 4))) return SC_EUNSUPPORTED;
     if (packed && last_ids) return SC_EUNSUPPORTED;
     const bool ed = (epilogue & 1) != 0;       // depth-normalising epilogue: a template parameter of the kernel
+    const bool planar = (epilogue & 4) != 0;   // render_colors as [C][D][H][W] planes (sc_rasterize_fwd_planar)
+    if (planar && (packed || ed || last_ids)) return SC_EUNSUPPORTED;
     if (variant >= 3 && tile_size == 16 && (D == 3 || D == 4)) {
         if ((int64_t)C * tile_width * tile_height >= (1 << 29)) return SC_EINVAL;
         const int total_tiles = C * tile_width * tile_height;
         const int n_blocks = tile_order ? sc_tile_order_fwd_items(total_tiles) : total_tiles;
         if (ed && last_ids) return SC_EUNSUPPORTED;       // (the epilogue is an inference form: sc_rasterize_fwd_ed passes none)
-#define SC_LAUNCH_WAVE(CD, TR, PK, EDP)                                                                             \
-    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR, PK, EDP>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, \
+#define SC_LAUNCH_WAVE(CD, TR, PK, EDP, ...)                                                                        \
+    hipLaunchKernelGGL((raster_fwd_wave_kernel<CD, TR, PK, EDP, ##__VA_ARGS__>), dim3(n_blocks), dim3(64), 0, sc_s(stream), means2d, \
                        conics, colors, opacities, backgrounds, tile_masks, NS, width, height, tile_width,           \
                        tile_height, total_tiles, isect_offsets, flatten_ids, (int)n_isects, render_colors,         \
                        render_alphas, last_ids, g_sc_raster_map, tile_order, tile_work SC_DIAG_ARG(g_sc_debug[1] & 0xff))
-        if (packed) { if (ed) SC_LAUNCH_WAVE(4, false, true, true); else SC_LAUNCH_WAVE(4, false, true, false); }
+        if (planar) { if (D == 4) SC_LAUNCH_WAVE(4, false, false, false, true); else SC_LAUNCH_WAVE(3, false, false, false, true); }
+        else if (packed) { if (ed) SC_LAUNCH_WAVE(4, false, true, true); else SC_LAUNCH_WAVE(4, false, true, false); }
         else if (D == 4) {
             if (ed) SC_LAUNCH_WAVE(4, false, false, true);
             else if (last_ids) SC_LAUNCH_WAVE(4, true, false, false);
@@ -615,6 +655,20 @@ extern "C" int sc_rasterize_fwd(const float* means2d, const float* conics, const
     return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
                               tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
                               render_colors, render_alphas, last_ids, tile_order, tile_work, stream, 0);
+}
+
+// render_colors stored as planes [C][D][H][W] (see raster_item<.., PLANAR>); inference form: no last_ids.  The wave kernel
+// only (tile 16, 3 or 4 channels): SC_EUNSUPPORTED otherwise, and the caller takes sc_rasterize_fwd.
+extern "C" int sc_rasterize_fwd_planar(const float* means2d, const float* conics, const float* colors,
+                                       const float* opacities, const float* backgrounds,
+                                       const uint8_t* tile_masks, int C, int N, int D, int width, int height,
+                                       int tile_size, int tile_width, int tile_height,
+                                       const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                       int64_t n_isects, float* render_colors, float* render_alphas,
+                                       const int32_t* tile_order, int32_t* tile_work, sc_stream_t stream) {
+    return rasterize_fwd_impl(means2d, conics, colors, opacities, backgrounds, tile_masks, C, N, D, width, height,
+                              tile_size, tile_width, tile_height, isect_offsets, flatten_ids, n_isects,
+                              render_colors, render_alphas, nullptr, tile_order, tile_work, stream, 4);
 }
 
 extern "C" int sc_rasterize_fwd_ed(const float* means2d, const float* conics, const float* colors,

@@ -39,14 +39,16 @@ def frames_for_rank(n_frames: int, rank: int, world: int) -> List[int]:
 
 
 def _hwc_view(x: torch.Tensor):
-    """[3,H,W] tensor that is a permuted view of an [H,W,C>=3] image -> (x itself: its first element IS pixel (0,0)
-    channel 0 of that image, pixel stride) or None.  (Read off the strides: building the permuted view costs ~2 us of
+    """[3,H,W] tensor that is a permuted view of an [H,W,C>=3] image, or three planes of a [C,H,W] one -> (x itself: its first
+    element IS pixel (0,0) channel 0 of that image, pixel stride, channel stride) or None.  (Read off the strides: building the permuted view costs ~2 us of
     host time per frame.)"""
     if x.dim() != 3 or x.shape[0] != 3:
         return None
     s0, s1, s2 = x.stride()
     if s0 == 1 and s2 >= 3 and s1 == x.shape[2] * s2:
-        return x, s2
+        return x, s2, 1
+    if s2 == 1 and s1 == x.shape[2] and s0 >= x.shape[1] * x.shape[2]:
+        return x, 1, s0            # planes (rendering.set_planar_output): pixel stride 1, channel stride s0
     return None
 
 
@@ -86,7 +88,18 @@ def to_uint8_frame(rgb_chw: torch.Tensor, acc: Optional[torch.Tensor] = None,
         if fg is not None and (sky_rgb_chw is None or (sky is not None and a.is_contiguous()
                                                       and a.dtype == torch.float32)):
             fast = _lib.fast()
-            if fast is not None:
+            if fg[2] != 1 or (sky is not None and sky[2] != 1):
+                if fast is not None:
+                    rc = fast.frame_composite_u8_strided(fg[0].data_ptr(), fg[1], fg[2], 0 if a is None else a.data_ptr(),
+                                                         0 if sky is None else sky[0].data_ptr(), 1 if sky is None else sky[1],
+                                                         1 if sky is None else sky[2], H * W, ROUNDING[rounding], out,
+                                                         _raw_stream(x))
+                else:
+                    rc = _lib.load().sc_frame_composite_u8_strided(
+                        fg[0].data_ptr(), fg[1], fg[2], None if a is None else a.data_ptr(),
+                        None if sky is None else sky[0].data_ptr(), 1 if sky is None else sky[1],
+                        1 if sky is None else sky[2], H * W, ROUNDING[rounding], out.data_ptr(), _raw_stream(x))
+            elif fast is not None:
                 rc = fast.frame_composite_u8(fg[0].data_ptr(), fg[1], 0 if a is None else a.data_ptr(),
                                              0 if sky is None else sky[0].data_ptr(), 0 if sky is None else sky[1],
                                              H * W, ROUNDING[rounding], out, _raw_stream(x))
@@ -264,6 +277,40 @@ class FrameGatherer:
         self._events.clear()
         for k in self.stats:
             self.stats[k] = 0 if isinstance(self.stats[k], int) else 0.0
+
+
+def make_stream(device, cus: Optional[int] = None, priority: Optional[int] = None):
+    """A HIP stream of `device` for the frame loop, wrapped for torch: confined to the first `cus` CUs of the chip's numbering
+    (the driver deals the mask bits round-robin over the XCDs: `cus` / 8 CUs of every XCD; include/street_crafter_amd.h,
+    sc_stream_create), or of the given `priority` (lower = more urgent; sc_stream_priority_range), else a plain
+    non-blocking stream.  The returned torch.cuda.ExternalStream keeps the raw handle alive until `destroy_stream`."""
+    import ctypes
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device(device)
+    out = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        if cus is not None:
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            cus = max(1, min(int(cus), total))
+            words = (total + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for i in range(cus):
+                mask[i // 32] |= 1 << (i % 32)
+            _lib.check(lib.sc_stream_create(0, ctypes.cast(mask, ctypes.c_void_p), words, ctypes.byref(out)), "sc_stream_create")
+        else:
+            lo, hi = ctypes.c_int(), ctypes.c_int()
+            _lib.check(lib.sc_stream_priority_range(ctypes.byref(lo), ctypes.byref(hi)), "sc_stream_priority_range")
+            pr = 0 if priority is None else max(min(int(priority), lo.value), hi.value)
+            _lib.check(lib.sc_stream_create(pr, None, 0, ctypes.byref(out)), "sc_stream_create")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+def destroy_stream(stream) -> None:
+    """Synchronises and destroys a stream made by make_stream."""
+    from . import _lib
+    stream.synchronize()
+    _lib.check(_lib.load().sc_stream_destroy(stream.cuda_stream), "sc_stream_destroy")
 
 
 def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst: int = 0,

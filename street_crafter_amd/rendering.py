@@ -804,6 +804,45 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 # a9 rasterize_to_pixels  (renderer.py:267-280)
 # ------------------------------------------------------------------------------------------
 _SCHED_SIZES = {}      # tiles -> (words of the work-hint buffer, items of the dispatch list)
+_PLANAR_OUT = {"on": True}
+
+
+def set_planar_output(enabled: bool) -> bool:
+    """Storage of rasterize_to_pixels' `render_colors` under no_grad (tile_size 16, 3 or 4 channels): True (default) = one plane
+    per channel, [C][D][H][W], returned as the permuted [C,H,W,D] view; False = interleaved as before.  Values, shapes and every
+    indexing expression are the same; what the reference's caller does with the result right behind the operator
+    (renderer.py:282-300: `[..., :-1]`, `[..., -1:] / alpha`, clamp, `.permute(2, 0, 1)`) becomes dense kernels instead of
+    strided ones (-10 us per 1920x1280 frame, tools/exp_glue_layout.py).  The tensor is not `is_contiguous()` in this form
+    (`.view(-1)` on it needs `.reshape`).  Training (anything requires grad) always takes the interleaved form.  Returns the
+    previous setting."""
+    prev, _PLANAR_OUT["on"] = _PLANAR_OUT["on"], bool(enabled)
+    return prev
+
+
+_RASTER_SIDE = {}      # device index -> {raw handle of the caller's stream (None = any): torch stream the rasterizer runs on}
+
+
+def set_raster_side_stream(device, side, main=None):
+    """Frame-loop option (dist.make_stream; bench.py --raster-cus / --raster-priority): the INFERENCE rasterizer of `device`
+    is launched on the stream `side` -- typically one confined to a subset of the CUs or of lower priority -- instead of on
+    the caller's current stream, fenced by events on both sides, so that the results and their ordering are unchanged.
+    With several frames in flight the one-wave workgroups of the VALU-bound rasterizer otherwise take every free wave slot
+    and the next frame's latency-bound intersection kernels (8..16-wave workgroups) wait for whole CUs to drain.
+    `main`: only rasterizer calls issued under this stream (a torch stream) use `side`; None = calls under any stream.
+    side=None removes the entry.  Returns the previous side stream of that (device, main)."""
+    idx = device if isinstance(device, int) else torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    tab = _RASTER_SIDE.setdefault(idx, {})
+    key = None if main is None else int(main.cuda_stream)
+    prev = tab.get(key)
+    if side is None:
+        tab.pop(key, None)
+        if not tab:
+            _RASTER_SIDE.pop(idx, None)
+    else:
+        tab[key] = side
+    return prev
 
 
 def reset_state(device=None) -> dict:
@@ -863,10 +902,43 @@ class _Rasterize(torch.autograd.Function):
         needs_bwd = any(ctx.needs_input_grad[:5])
         order, work = _sched_of(isect_offsets, C * tw * th)
         fast = _lib.fast()
-        if fast is not None:
+        st = _stream(means2d)
+        side = cur = None
+        if _RASTER_SIDE and not needs_bwd:         # set_raster_side_stream: the kernel runs on another stream, fenced by events
+            tab = _RASTER_SIDE.get(dev.index)
+            side = (tab.get(st) or tab.get(None)) if tab else None
+            if side is not None:
+                # (the outputs are allocated under the caller's stream as always: every later use of them on that stream is
+                #  behind the second event, and the inputs outlive the kernel for the same reason)
+                cur = torch.cuda.current_stream(dev)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                side.wait_event(ev)
+                st = side.cuda_stream
+        rc = -3
+        last_ids = None
+        if _PLANAR_OUT["on"] and not needs_bwd and int(tile_size) == 16 and D in (3, 4):
+            # inference: one plane per channel behind the same [C,H,W,D] indexing (set_planar_output); -3 = not this kernel
+            if fast is not None:
+                rc, render_colors, render_alphas = fast.rasterize_fwd_planar(
+                    means2d, conics, colors, opacities, backgrounds, masks, int(width), int(height), int(tile_size),
+                    isect_offsets, flatten_ids, order, work, st)
+            else:
+                planes = torch.empty((C, D, height, width), dtype=torch.float32, device=dev)
+                render_alphas = torch.empty((C, height, width, 1), dtype=torch.float32, device=dev)
+                rc = lib.sc_rasterize_fwd_planar(_p(means2d), _p(conics), _p(colors), _p(opacities), _p(backgrounds),
+                                                 _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
+                                                 _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(), _p(planes),
+                                                 _p(render_alphas), _p(order), _p(work), st)
+                render_colors = planes.permute(0, 2, 3, 1)
+            if rc not in (0, -3):
+                _lib.check(rc, "sc_rasterize_fwd_planar")
+        if rc == 0:
+            pass
+        elif fast is not None:
             rc, render_colors, render_alphas, last_ids = fast.rasterize_fwd(
                 means2d, conics, colors, opacities, backgrounds, masks, int(width), int(height), int(tile_size),
-                isect_offsets, flatten_ids, bool(needs_bwd), order, work, _stream(means2d))
+                isect_offsets, flatten_ids, bool(needs_bwd), order, work, st)
             if rc:
                 _lib.check(rc, "sc_rasterize_fwd")
         else:
@@ -877,8 +949,12 @@ class _Rasterize(torch.autograd.Function):
                                             _p(masks), C, N, D, int(width), int(height), int(tile_size), tw, th,
                                             _p(isect_offsets), _p(flatten_ids), flatten_ids.numel(),
                                             _p(render_colors), _p(render_alphas), _p(last_ids), _p(order), _p(work),
-                                            _stream(means2d)),
+                                            st),
                        "sc_rasterize_fwd")
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            cur.wait_event(ev)
         e = _EMPTY.get(dev)
         if e is None:
             e = _EMPTY[dev] = torch.empty(0, device=dev)
