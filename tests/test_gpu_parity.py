@@ -1797,6 +1797,132 @@ def test_render_sharded_two_frames_in_flight_is_identical(ops):
     assert not torch.equal(seq[0], seq[5])
 
 
+@pytest.mark.parametrize("w,h,D,use_bg,use_mask", [(256, 160, 4, False, False), (333, 211, 4, True, True),
+                                                     (402, 130, 3, True, False), (128, 96, 3, False, True)])
+def test_planar_output_is_the_same_tensor_by_value(ops, w, h, D, use_bg, use_mask):
+    """rendering.set_planar_output: under no_grad rasterize_to_pixels stores render_colors as one plane per channel and
+    hands out the permuted [C,H,W,D] view (renderer.py:282-300 slices it channel-wise).  Values, shape and the frame the
+    caller makes of it are identical to the interleaved form; widths that are not multiples of 4 / 2 take the scalar
+    stores; a call that requires grad takes the interleaved form."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.dist import to_uint8_frame
+    sc = make_scene(30_000, seed=21, z_range=(1.0, 30.0), scale_range=(0.01, 0.4))
+    cam = make_camera(w, h, 300.0, 300.0)
+    R = ops
+    with torch.no_grad():
+        radii, m2, d, con, comp = _project(R, sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), cam.viewmat.numpy(),
+                                           cam.K.numpy(), w, h, 0.001, 1000.0)
+        tw, th = (w + 15) // 16, (h + 15) // 16
+        _, ids, fids = R.isect_tiles(m2, radii, d, 16, tw, th, n_cameras=1)
+        off = R.isect_offset_encode(ids, 1, tw, th)
+        g = torch.Generator().manual_seed(3)
+        colors = torch.rand(1, sc.n, D, generator=g).to(DEV)
+        opac = (sc.opacities[None, :, 0].to(DEV) * comp).contiguous()
+        bg = torch.rand(1, D, generator=g).to(DEV) if use_bg else None
+        masks = (torch.rand(1, th, tw, generator=g) > 0.2).to(DEV) if use_mask else None
+        outs = {}
+        for planar in (False, True):
+            prev = rendering.set_planar_output(planar)
+            try:
+                outs[planar] = R.rasterize_to_pixels(m2, con, colors, opac, w, h, 16, off, fids, backgrounds=bg, masks=masks)
+            finally:
+                rendering.set_planar_output(prev)
+        (c0, a0), (c1, a1) = outs[False], outs[True]
+        assert c0.shape == c1.shape == (1, h, w, D) and c0.is_contiguous()
+        assert c1.stride() == (D * h * w, w, 1, h * w)             # planes behind the same indexing
+        assert torch.equal(c0, c1) and torch.equal(a0, a1)
+        # what the caller does with it (renderer.py:282-300), and the uint8 frame of it
+        f0 = to_uint8_frame(torch.clamp(c0[..., :3], 0.0, 1.0)[0].permute(2, 0, 1))
+        f1 = to_uint8_frame(torch.clamp(c1[..., :3], 0.0, 1.0)[0].permute(2, 0, 1))
+        assert torch.equal(f0, f1) and int(f0.max()) > 0
+        if D == 4:
+            assert torch.equal(c0[..., -1:] / a0.clamp(min=1e-10), c1[..., -1:] / a1.clamp(min=1e-10))
+    colors.requires_grad_(True)
+    c2, _ = R.rasterize_to_pixels(m2, con, colors, opac, w, h, 16, off, fids, backgrounds=bg, masks=masks)
+    assert c2.is_contiguous() and torch.equal(c2.detach(), c0)
+
+
+def test_rasterizer_on_a_cu_masked_or_prioritised_side_stream_renders_the_same_frames(ops):
+    """rendering.set_raster_side_stream + dist.make_stream (sc_stream_create): the inference rasterizer handed to a stream
+    confined to 64 of the CUs, or of the lowest priority, fenced by events -- frames identical to the plain loop, with two
+    frames in flight as well."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.dist import destroy_stream, make_stream, to_uint8_frame
+    from harness.caller import render_gaussians
+    sc = make_scene(80_000, seed=13).to(DEV)
+    cams = [make_camera(640, 400, 600.0, 600.0, yaw=0.02 * i, shift=(0.1 * i, 0.0, 0.0)).to(DEV) for i in range(6)]
+    dev = torch.device(DEV, torch.cuda.current_device())
+
+    def frames(mains=None):
+        out = []
+        home = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            for f, cam in enumerate(cams):
+                if mains:
+                    torch.cuda.set_stream(mains[f % len(mains)])
+                out.append(to_uint8_frame(render_gaussians(sc, cam)["rgb"]))
+        torch.cuda.set_stream(home)
+        torch.cuda.synchronize()
+        return out
+
+    ref = frames()
+    for kw in (dict(cus=64), dict(priority=100)):
+        side = make_stream(dev, **kw)
+        mains = [make_stream(dev), make_stream(dev)]
+        try:
+            assert rendering.set_raster_side_stream(dev, side) is None
+            got = frames()
+            got2 = frames(mains)
+        finally:
+            rendering.set_raster_side_stream(dev, None)
+            torch.cuda.synchronize()
+            for st in [side] + mains:
+                destroy_stream(st)
+        for a, b, c in zip(ref, got, got2):
+            assert torch.equal(a, b) and torch.equal(a, c)
+    assert not rendering._RASTER_SIDE
+
+
+@pytest.mark.parametrize("which", ["golden", "iid", "big_splats", "two_cameras", "odd_frame"])
+def test_isect_pull_route_is_bit_exact(ops, golden_dir, which):
+    """sc_set_option("isect_pull", 1): every super-tile bucket's sort workgroup gathers its records itself from a (size class,
+    anchor)-sorted payload (no scatter launch, no records buffer).  Same tensors as the scatter route and the oracle, bit for
+    bit, incl. oversized buckets (big_pull + big_split), two cameras, and frames that are not whole super-tiles."""
+    from street_crafter_amd import _lib, rendering
+    if which == "golden":
+        g = _load(golden_dir, "pipeline_small.npz")
+        m2, radii, d, tw, th, C = _t(g["means2d"])[None], _t(g["radii"], torch.int32)[None], _t(g["depths"])[None], 8, 6, 1
+    else:
+        cfg = {"iid": (120_000, 1, 960, 640, (0.005, 0.15)), "big_splats": (25_000, 1, 1920, 1280, (0.5, 4.0)),
+               "two_cameras": (60_000, 2, 640, 400, (0.01, 0.3)), "odd_frame": (20_000, 1, 333, 211, (0.01, 0.6))}[which]
+        n, C, w, h, sr = cfg
+        sc = make_scene(n, seed=31, scale_range=sr)
+        cams = [make_camera(w, h, 2050.0 * w / 1920.0, 2050.0 * w / 1920.0, yaw=0.2 * c) for c in range(C)]
+        with torch.no_grad():
+            radii, m2, d, _, _ = ops.fully_fused_projection(
+                sc.means.to(DEV), None, sc.quats.to(DEV), sc.scales.to(DEV), torch.stack([c.viewmat for c in cams]).to(DEV),
+                torch.stack([c.K for c in cams]).to(DEV), w, h, near_plane=0.001, far_plane=1000.0)
+        tw, th = (w + 15) // 16, (h + 15) // 16
+    e_tpg, e_ids, e_f = O.isect_tiles(_np(m2), _np(radii), _np(d), 16, tw, th, n_cameras=C)
+    e_off = O.isect_offset_encode(e_ids, C, tw, th)
+    for pull in (1, 0):
+        prev = _lib.set_option("isect_pull", pull)
+        rendering.reset_state()
+        try:
+            for rep in range(2):           # (second call: predicted sizes, deferred settle)
+                tpg, ids, fids = ops.isect_tiles(m2, radii, d, 16, tw, th, n_cameras=C)
+                if which == "big_splats" and rep == 0:      # the case is there for the oversized-bucket path
+                    assert list(rendering._BIN_LAST_META.values())[-1][2] > _lib.load().sc_isect_bin_bucket_capacity()
+                off = ops.isect_offset_encode(ids, C, tw, th)
+                np.testing.assert_array_equal(_np(tpg), e_tpg)
+                np.testing.assert_array_equal(_np(off), e_off)
+                np.testing.assert_array_equal(_np(torch.as_tensor(fids)), e_f)
+                np.testing.assert_array_equal(_np(torch.as_tensor(ids)), e_ids)
+        finally:
+            _lib.set_option("isect_pull", prev)
+            rendering.reset_state()
+
+
 def test_rccl_gather_ring_at_world_one(ops):
     """The RCCL transport of the frame gather, executed on the one GPU a box has (VERDICT r2 missing 1): a child
     process runs init_process_group("nccl", world_size=1, device_id=...) and pushes frames through the REAL
@@ -2108,5 +2234,6 @@ def test_full_size_properties_1m(ops):
         got_c = _np(out["_render_colors"])[0, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
         got_a = _np(out["_render_alphas"])[0, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16]
         ok = ~exp[3][0]
-        np.testing.assert_allclose(got_c[..., :3][ok], exp[0][0][..., :3][ok], rtol=0, atol=2e-4)
-        np.testing.assert_allclose(got_a[ok], exp[1][0][ok], rtol=0, atol=2e-4)
+        # (north_star's bar: 1e-4 abs on the pixels the oracle does not flag threshold-unstable)
+        np.testing.assert_allclose(got_c[..., :3][ok], exp[0][0][..., :3][ok], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(got_a[ok], exp[1][0][ok], rtol=0, atol=1e-4)
