@@ -38,7 +38,7 @@ class Develop(develop):
 
 setup(
     name="street_crafter_amd",
-    version="0.3.0",
+    version="0.4.0",
     description="MI355X (gfx950) HIP implementation of the gsplat / simple_knn operators StreetCrafter calls",
     packages=find_packages(include=["street_crafter_amd", "street_crafter_amd.*", "gsplat", "gsplat.*", "simple_knn",
                                     "simple_knn.*"]),

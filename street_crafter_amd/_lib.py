@@ -170,7 +170,10 @@ def _fast_locked():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         if mod.abi_version().encode() != load().sc_version():
-            raise ImportError("street_crafter_amd: _sc_fast.so and libstreet_crafter_hip.so are different builds")
+            # (each binary carries the digest of the include/street_crafter_amd.h it was compiled against)
+            raise ImportError("street_crafter_amd: _sc_fast.so and libstreet_crafter_hip.so were built against different "
+                              f"editions of the C ABI ({mod.abi_version()!r} vs {load().sc_version().decode()!r}): "
+                              "python -m street_crafter_amd.build")
         _fast = mod
     return _fast
 

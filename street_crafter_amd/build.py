@@ -33,6 +33,13 @@ COMMON_FLAGS = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-Wall",
                 "-fno-gpu-rdc"]
 
 
+def abi_hash() -> str:
+    """Digest of the C-ABI header: compiled into the library (sc_version) and into the binding layer (abi_version)."""
+    import hashlib
+    with open(os.path.join(HERE, "..", "include", "street_crafter_amd.h"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
@@ -62,7 +69,8 @@ def _compile(src, force, verbose, diag=False):
     # (SC_EXP_DEFS: extra -D flags for the DIAGNOSTIC build only -- kernel experiments are A/B-ed as shipped library
     #  vs diagnostic library, tools/ab_lib.py; the shipped build never sees them)
     extra = os.environ.get("SC_EXP_DEFS", "").split() if diag else []
-    cmd = [_hipcc(), *COMMON_FLAGS, *(["-DSC_DIAG", *extra] if diag else []), "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *COMMON_FLAGS, f'-DSC_ABI_HASH="{abi_hash()}"', *(["-DSC_DIAG", *extra] if diag else []), "-c",
+           os.path.join(CSRC, src), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -100,7 +108,7 @@ def build_binding(force=False, verbose=False):
     import torch
     from torch.utils import cpp_extension as ce
     src = os.path.join(CSRC, "binding.cpp")
-    deps = [src, os.path.join(HERE, "..", "include", "street_crafter_amd.h")]
+    deps = [src, os.path.join(HERE, "..", "include", "street_crafter_amd.h"), LIB]     # (a rebuilt library: rebuild the binding too)
     if not os.path.exists(LIB):
         raise RuntimeError("build the HIP library first")
     if not force and not _stale(BINDING, deps):
@@ -108,7 +116,7 @@ def build_binding(force=False, verbose=False):
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", BINDING,
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-DTORCH_EXTENSION_NAME=_sc_fast",
-           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations",
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-Wno-deprecated-declarations", f'-DSC_ABI_HASH="{abi_hash()}"',
            *[f"-I{i}" for i in ce.include_paths()], f"-I{sysconfig.get_paths()['include']}",
            f"-L{LIBDIR}", "-lstreet_crafter_hip", f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python",
            "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]

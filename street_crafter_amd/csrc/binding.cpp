@@ -21,6 +21,10 @@
 
 #include "../../include/street_crafter_amd.h"
 
+#ifndef SC_ABI_HASH
+#define SC_ABI_HASH "unhashed"
+#endif
+
 namespace {
 
 using at::Tensor;
@@ -503,7 +507,8 @@ int frame_composite_u8(int64_t fg_ptr, int64_t fg_stride, int64_t acc_ptr, int64
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "street_crafter_amd: compiled Python <-> C-ABI binding layer (allocation + call per operator)";
-    m.def("abi_version", []() { return std::string(sc_version()); });
+    // (the header digest THIS binary was compiled against, not the loaded library's: _lib.py compares the two)
+    m.def("abi_version", []() { return std::string("street_crafter_amd 0.4.0 (gfx950) abi:" SC_ABI_HASH); });
     m.def("projection_fwd", &projection_fwd);
     m.def("projection_bwd", &projection_bwd);
     m.def("isect_bin_count", &isect_bin_count);

@@ -3,10 +3,16 @@
 #include <string.h>
 #include <time.h>
 
+// SC_ABI_HASH: a digest of include/street_crafter_amd.h, handed to BOTH binaries by build.py (this library and the binding
+// layer, csrc/binding.cpp): a binding layer compiled against another edition of the header than the library beside it
+// (signatures!) refuses to load (_lib.py) instead of calling through stale prototypes.
+#ifndef SC_ABI_HASH
+#define SC_ABI_HASH "unhashed"
+#endif
 #ifdef SC_DIAG
-extern "C" const char* sc_version(void) { return "street_crafter_amd 0.3.0 (gfx950, DIAGNOSTIC build)"; }
+extern "C" const char* sc_version(void) { return "street_crafter_amd 0.4.0 (gfx950, DIAGNOSTIC build) abi:" SC_ABI_HASH; }
 #else
-extern "C" const char* sc_version(void) { return "street_crafter_amd 0.3.0 (gfx950)"; }
+extern "C" const char* sc_version(void) { return "street_crafter_amd 0.4.0 (gfx950) abi:" SC_ABI_HASH; }
 #endif
 
 extern "C" const char* sc_target_arch(void) { return "gfx950"; }

@@ -72,20 +72,32 @@ class LazyTensor(torch.Tensor):
     def resolve_shape(self) -> torch.Tensor:
         """Runs the pending resolver (if any): afterwards shape and storage are final.  Returns self."""
         resolve = self.__dict__.get("_sc_resolve")
-        if resolve is not None:
+        if resolve is not None and not self.__dict__.get("_sc_busy"):
+            # the resolver is dropped only AFTER it has run: if it raises (more than 2^31 - 1 intersections, an allocation or
+            # HIP error in the exact-size relaunch) it stays, and EVERY later observation raises again instead of handing out
+            # the zero-length placeholder as if it were the list (ADVICE r3)
+            self.__dict__["_sc_busy"] = True
+            try:
+                with torch._C.DisableTorchFunctionSubclass():
+                    resolve(self)
+            finally:
+                self.__dict__["_sc_busy"] = False
             self.__dict__["_sc_resolve"] = None
-            with torch._C.DisableTorchFunctionSubclass():
-                resolve(self)
         return self
 
     def materialize(self) -> torch.Tensor:
         """Settles the shape, runs the pending fill (if any) and returns self."""
         self.resolve_shape()
         fill = self.__dict__.get("_sc_fill")
-        if fill is not None:
-            self.__dict__["_sc_fill"] = None
-            with torch._C.DisableTorchFunctionSubclass():
-                fill(self)
+        if fill is not None and not self.__dict__.get("_sc_busy"):
+            self.__dict__["_sc_busy"] = True
+            try:
+                with torch._C.DisableTorchFunctionSubclass():
+                    fill(self)
+            finally:
+                self.__dict__["_sc_busy"] = False
+            if self.__dict__.get("_sc_fill") is fill:       # (a fill that failed stays pending, like the resolver)
+                self.__dict__["_sc_fill"] = None
         return self
 
     def _observe(self, contents: bool):

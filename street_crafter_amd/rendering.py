@@ -304,6 +304,13 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                None, None, st, viewmats=view_cams, defer=True)
         if res is not None:
             return res[:3]
+    return _isect_tiles_radix(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height, sort, st)
+
+
+def _isect_tiles_radix(lib, means2d, radii, depths, C, N, tile_size, tile_width, tile_height, sort, st):
+    """The reference-shaped route: count -> emit -> device-wide radix sort (sort=False, frames outside the bucketed
+    path's limits, and the on-GPU cross-check of the bucketed route)."""
+    dev = means2d.device
     tiles_per_gauss = torch.empty((C, N), dtype=torch.int32, device=dev)
     total_dev = torch.empty(1, dtype=torch.int64, device=dev)
     wsb = lib.sc_isect_workspace_bytes(C * N)
@@ -330,6 +337,17 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                                                        n_isects, 32 + tile_bits + cam_bits, _p(sws),
                                                        sws.numel(), st), "sc_radix_sort_pairs_u64_i32")
     return tiles_per_gauss, isect_ids, flatten_ids
+
+
+_WARNED = set()
+
+
+def _warn_once(key, msg, *args):
+    """One WARNING per process and key (logging, logger "street_crafter_amd")."""
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import logging
+        logging.getLogger("street_crafter_amd").warning(msg, *args)
 
 
 def _check_isect_count(n_isects, C, N, tile_width, tile_height):
@@ -504,8 +522,9 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         if prev_pending is not None:
             try:
                 prev_pending.resolve()
-            except Exception:      # noqa: BLE001  (kept on the pending call: its own tensors raise it when looked at)
-                pass
+            except Exception as e:      # noqa: BLE001  (kept on the pending call: its own tensors raise it when looked at)
+                _warn_once("settle_prev", "isect_tiles: settling the previous, never observed call failed (%s: %s); its own "
+                           "tensors raise the error when they are looked at", type(e).__name__, e)
     meta_np, meta_ptr = slot[1], slot[3]
     slot[2] += 1
     seq = slot[2]
@@ -552,6 +571,9 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         waited = (fast.wait_i64(meta_ptr + 32, seq, 2_000_000) if fast is not None
                   else lib.sc_wait_i64(meta_ptr + 32, seq, 2_000_000))
         if waited != 0:
+            # (the settle may run under another current stream than `st` -- the thread's next isect_tiles, reset_state -- and
+            #  a copy on THAT stream would not be ordered behind the count kernels: wait for the producer's stream first)
+            torch.cuda.ExternalStream(st, device=dev).synchronize()
             return tuple(int(v) for v in meta_dev.cpu().tolist())
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
@@ -664,12 +686,11 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         def settle_deferred():
             res = settle()
             if res is None:       # outside the bucketed path's limits after all: the reference-shaped route, now
-                prev = set_isect_mode("radix")
-                try:
-                    with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
-                        _, ids2, fids2 = isect_tiles(means2d, radii, depths, tile_size, tile_width, tile_height)
-                finally:
-                    set_isect_mode(prev)
+                # (called directly: switching the process-wide mode around a nested isect_tiles would send a concurrent
+                #  call of another host thread down the radix route too -- ADVICE r3)
+                with torch.cuda.stream(torch.cuda.ExternalStream(st, device=dev)):
+                    _, ids2, fids2 = _isect_tiles_radix(lib, means2d, radii, depths, C, N, tile_size, tile_width,
+                                                        tile_height, True, st)
                 state["n"] = fids2.numel()
                 pend_ids = pending.ids_ref() if pending.ids_ref is not None else None
                 if pend_ids is not None:
@@ -862,8 +883,9 @@ def reset_state(device=None) -> dict:
             if pend is not None:
                 try:
                     pend.resolve()
-                except Exception:      # noqa: BLE001  (stays on the pending call's own tensors)
-                    pass
+                except Exception as e:      # noqa: BLE001  (stays on the pending call's own tensors)
+                    _warn_once("settle_reset", "reset_state: settling a never observed isect_tiles call failed (%s: %s)",
+                               type(e).__name__, e)
     dropped = {}
     for name, table in (("predictions", _BIN_PREDICTION), ("history", _BIN_HISTORY), ("last_meta", _BIN_LAST_META),
                         ("tile_work", _TILE_WORK), ("view_registry", _VIEW_REGISTRY)):

@@ -434,6 +434,42 @@ def test_lazy_tensor_with_a_deferred_shape():
     assert type(t.plain()) is torch.Tensor and t.plain().shape == (4,) and t.plain().data_ptr() == cap.data_ptr()
 
 
+def test_lazy_tensor_whose_resolver_fails_keeps_failing():
+    """a resolver (or fill) that raises -- more than 2^31 - 1 intersections, an allocation or HIP error in the
+    exact-size relaunch -- must raise on EVERY observation; the zero-length placeholder must never be handed out as if it
+    were the settled list (a caller that catches the error and rasterizes again would otherwise get a blank frame)."""
+    import pytest
+    import torch
+    from street_crafter_amd.lazy import LazyTensor
+    from street_crafter_amd.rendering import _PendingIsect
+    calls = []
+
+    def settle():
+        calls.append(1)
+        raise RuntimeError("isect_tiles: too many intersections")
+
+    pend = _PendingIsect(settle)                       # what isect_tiles' deferred tensors carry
+    z = LazyTensor(torch.zeros(0, dtype=torch.int32), None, pend.resolve)
+    for observe in (lambda t: t.shape, lambda t: t.numel(), lambda t: t.plain(), lambda t: t + 1, lambda t: t.shape):
+        with pytest.raises(RuntimeError, match="too many intersections"):
+            observe(z)
+        assert not z.is_resolved
+    assert len(calls) == 1                             # the settle itself ran once; its error is what every observation raises
+    assert z.dtype == torch.int32 and z.ndim == 1      # (shape-free questions still need no settle)
+    # a fill that fails stays pending as well
+    n = []
+
+    def fill(t):
+        n.append(1)
+        raise ValueError("rebuild failed")
+
+    y = LazyTensor(torch.zeros(3, dtype=torch.int64), fill)
+    for _ in range(2):
+        with pytest.raises(ValueError):
+            y.tolist()
+    assert len(n) == 2 and not y.is_materialized and y.shape == (3,)
+
+
 def test_compiled_binding_layer_loads_and_refuses_cpu_tensors(lib):
     """csrc/binding.cpp -> lib/_sc_fast.so: the default host path.  It must be the same build as the library (version
     string), export one entry per hot operator call, and refuse tensors that are not on a HIP device before anything
@@ -443,6 +479,10 @@ def test_compiled_binding_layer_loads_and_refuses_cpu_tensors(lib):
     fast = _lib.fast()
     assert fast is not None and os.path.exists(_lib.FAST_PATH)
     assert fast.abi_version().encode() == lib.sc_version()
+    # both binaries carry the digest of the header they were compiled against (a stale binding next to a rebuilt library with
+    # changed signatures must refuse to load)
+    from street_crafter_amd import build as _b
+    assert fast.abi_version().endswith("abi:" + _b.abi_hash()) and lib.sc_version().decode().endswith("abi:" + _b.abi_hash())
     for name in ("projection_fwd", "projection_bwd", "isect_bin_count", "isect_bin_sort", "wait_i64", "sh_fwd", "sh_bwd",
                  "rasterize_fwd", "rasterize_bwd", "projection_sh_fwd", "rasterize_fwd_packed", "frame_composite_u8"):
         assert callable(getattr(fast, name)), name
