@@ -70,6 +70,12 @@ def parse(argv=None):
     ap.add_argument("--isect-mode", choices=["bin", "radix"], default=None)
     ap.add_argument("--raster-variant", type=int, default=None)
     ap.add_argument("--stage-times", action="store_true", help="print per-operator times to stderr")
+    ap.add_argument("--interleaved-output", action="store_true",
+                    help="A/B: rasterize_to_pixels stores render_colors interleaved [C,H,W,D] as gsplat does instead of one plane "
+                         "per channel behind the same indexing (rendering.set_planar_output; profiles/r04_planar_output_ab.txt)")
+    ap.add_argument("--raster-cus", type=int, default=None,
+                    help="A/B: every frame stream hands its rasterizer to a side stream confined to this many CUs "
+                         "(dist.make_stream / rendering.set_raster_side_stream; measured slower: profiles/r04_cu_mask_ab.txt)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip every secondary measurement (keeps rocprof profiles of the headline clean)")
     ap.add_argument("--skip", default="", help="comma list of secondary lines to skip: single_stream,two_in_flight,fused,"
@@ -154,6 +160,28 @@ def cpu_baseline(scene, cam, W, H, hip_frame_fn, budget_s=30.0):
     got = hip_frame_fn()
     ref_rgb = np.clip(exp["render_colors"][0, ..., :3], 0.0, 1.0)
     err = np.abs(got["rgb"] - ref_rgb).max(axis=-1)
+    # EVERY pixel beyond the flat 1e-4 bar (threshold-unstable or not) gets a verdict from the float64 blend of the same
+    # fp32 inputs (oracle/blend_f64.py: a pixel is right iff it is within 1e-4 of one of the float64 outcomes, or at least
+    # as close to it as the fp32 oracle's own pixel): "all pixels" has a judge, not an exclusion window
+    from oracle import blend_f64 as B64
+    ys, xs = np.nonzero(err > 1e-4)
+    order = np.argsort(-err[ys, xs])[:256]
+    f64 = {"f64_judged": 0, "f64_failed": 0, "f64_not_judged": int(max(0, len(ys) - 256)), "worst_hip_vs_f64": 0.0,
+           "worst_oracle_fp32_vs_f64": 0.0}
+    inputs_same = bool(np.array_equal(got["colors"].view(np.uint32), exp["colors"].view(np.uint32)) and
+                       np.array_equal(got["opacities"].view(np.uint32), exp["opacities"].view(np.uint32)) and
+                       np.array_equal(got["means2d"].view(np.uint32), exp["means2d"].view(np.uint32)) and
+                       np.array_equal(got["conics"].view(np.uint32), exp["conics"].view(np.uint32)))
+    if len(order):
+        scale = np.maximum(1.0, np.abs(exp["render_colors"][0]).max(axis=(0, 1)))      # (depth channel: metres)
+        rows = B64.judge_pixels(list(zip(xs[order], ys[order])), W, 16, exp["isect_offsets"], exp["flatten_ids"],
+                                exp["means2d"], exp["conics"], exp["colors"], exp["opacities"],
+                                {"hip": (got["render_colors"], got["render_alphas"]),
+                                 "oracle32": (exp["render_colors"][0], exp["render_alphas"][0])}, scale=scale)
+        f64.update(f64_judged=len(rows),
+                   f64_failed=sum(not (r["hip"]["err"] <= max(1e-4, r["oracle32"]["err"])) for r in rows),
+                   worst_hip_vs_f64=max(r["hip"]["err"] for r in rows),
+                   worst_oracle_fp32_vs_f64=max(r["oracle32"]["err"] for r in rows))
     # pixels where some alpha / transmittance sits within 2e-5 (relative) of a hard threshold can legitimately
     # flip on a 1-ulp exp difference (the oracle flags them); all-pixel figures are reported beside the stable ones
     stable = ~exp["unstable"][0]
@@ -165,6 +193,11 @@ def cpu_baseline(scene, cam, W, H, hip_frame_fn, budget_s=30.0):
         "pixels_over_1e-4": int((err > 1e-4).sum()),
         "pixels_over_1e-4_among_stable": int((err[stable] > 1e-4).sum()),
         "n_pixels": int(err.size),
+        **f64,
+        "f64_what": "every pixel over 1e-4 vs the fp32 oracle (stable or not, the 256 worst at most) against oracle/blend_f64.py: "
+                    "float64 blend of the SAME fp32 rasterizer inputs (bit-identical on both sides: "
+                    f"{inputs_same}), all outcomes of decisions no fp32 evaluation can resolve enumerated; failed = farther than "
+                    "1e-4 from every outcome AND farther than the fp32 oracle's own pixel",
         "isect_ids_and_flatten_ids_bit_exact": bool(np.array_equal(got["isect_ids"], exp["isect_ids"]) and
                                                     np.array_equal(got["flatten_ids"], exp["flatten_ids"])),
         "radii_bit_exact": bool(np.array_equal(got["radii"], exp["radii"])),
@@ -407,6 +440,8 @@ def run_rank(args):
             rendering.set_deferred_isect(False)
         if args.raster_variant is not None:
             _lib.set_option("raster_fwd", args.raster_variant)
+        if args.interleaved_output:
+            rendering.set_planar_output(False)
         if args.scene_ply:
             # a scene in the reference's point_cloud.ply layout (street_crafter_amd/scene_io.py); actors, if
             # any, are placed with identity poses.  Not the headline workload: the metric string stays S-1M's.
@@ -433,6 +468,13 @@ def run_rank(args):
     gatherer = FrameGatherer((H, W, 3), dev, dst=0, batch=args.gather_batch, reserve_rounds=reserve,
                              force_collective=bool(args.force_gather and world == 1 and not selftest))
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if (not selftest and n_streams > 1) else None
+    side_streams = []
+    if args.raster_cus and not selftest:
+        from street_crafter_amd.dist import make_stream
+        for m in (streams or [torch.cuda.current_stream(dev)]):
+            side_streams.append(make_stream(dev, cus=args.raster_cus))
+            rendering.set_raster_side_stream(dev, side_streams[-1], main=m)
+
     def recorder():
         return {"events": {}, "n_isects": [], "frame_ev": [], "probe_ev": []}
 
@@ -879,6 +921,15 @@ def run_rank(args):
             secondary["single_stream"].update({"stage_ms": st1, "operators": ops1, "roofline": roof1,
                                                "frame_ms_device": percentiles([a.elapsed_time(b) for a, b in
                                                                                single_rec["frame_ev"]])})
+        ss = secondary.get("single_stream")
+        if world == 1 and ss is not None:
+            # SURVEY 8(d)'s literal timing (one frame at a time on the current stream), kept NEXT TO the headline keys so that a
+            # truncated tail of the line cannot lose it; the full record stays under "single_stream"
+            line["single_stream_summary"] = {
+                "value": ss["value"], "unit": "frames/s", "ms_per_step": ss["ms_per_step"], "frames_in_flight": 1,
+                "frac_of_hbm_roofline_wall": ss["value"] / (HBM_PEAK / b_alg),
+                "what": "the same K frames ONE at a time (SURVEY 8d's timing method); `value` above keeps "
+                        f"{n_streams} frames in flight"}
         line.update({
             "config": {"workload": (f"scene file {os.path.basename(args.scene_ply)} ({args.n_gauss} Gaussians)"
                                     if args.scene_ply else f"S-{args.n_gauss // 1000}k") +
@@ -888,6 +939,9 @@ def run_rank(args):
                                    f"uint8 frames gathered to rank 0 {gatherer.batch} per collective",
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
                        "isect_mode": rendering._ISECT_MODE["mode"], "frames_in_flight": n_streams,
+                       "render_colors_storage": "planar (one plane per channel behind the [C,H,W,D] indexing)"
+                                                if rendering._PLANAR_OUT["on"] else "interleaved",
+                       "raster_side_stream_cus": args.raster_cus,
                        "isect_speculation": dict(spec, what="isect_tiles calls of the headline run incl. warm-up: "
                                                  "speculative_ok = the scatter + sort launched with sizes predicted "
                                                  "from the previous frame ran (no host wait in front of them); "
@@ -937,7 +991,11 @@ def run_rank(args):
                 with torch.no_grad():
                     o = render_gaussians(scene, cams[0], return_intermediates=True)
                 return {"rgb": o["rgb"].permute(1, 2, 0).cpu().numpy(), "isect_ids": o["_isect_ids"].cpu().numpy(),
-                        "flatten_ids": o["_flatten_ids"].cpu().numpy(), "radii": o["_radii"][0].cpu().numpy()}
+                        "flatten_ids": o["_flatten_ids"].cpu().numpy(), "radii": o["_radii"][0].cpu().numpy(),
+                        "render_colors": o["_render_colors"][0].cpu().numpy(),
+                        "render_alphas": o["_render_alphas"][0].cpu().numpy(), "colors": o["_colors"][0].cpu().numpy(),
+                        "opacities": o["_opacities"][0].cpu().numpy(), "means2d": o["_means2d"][0].cpu().numpy(),
+                        "conics": o["_conics"][0].cpu().numpy()}
 
             line["cpu_baseline"], line["parity"] = cpu_baseline(scene, cams[0], W, H, hip_frame)
         if args.stage_times:

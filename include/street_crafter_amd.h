@@ -322,6 +322,13 @@ int sc_stream_priority_range(int* least, int* greatest);
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Select a kernel variant at run time (for A/B measurements in one process).
+ *   key "proj_clamp": the clamp of x/z, y/z in fully_fused_projection's EWA Jacobian (forward, fused forward and backward):
+ *                     0 = +-1.3 tan(fov/2) (upstream gsplat v1.0-1.3; default), 1 = [-(cx/fx + 0.3 tan), (W - cx)/fx +
+ *                     0.3 tan] (v1.4+).  The two agree for a centred principal point.
+ *   key "radius_floor": the floor under the discriminant of the 3-sigma radius, sqrt(max(floor, b^2 - det)):
+ *                     0 = 0.01 (gsplat v1.x; default), 1 = 0.1 (the original Inria rasterizer and early forks).
+ *                     The reference installs an UNPINNED gsplat fork (README.md:35): INTEGRATION.md says how to tell which
+ *                     pair a checkout has.  Environment: SC_PROJ_CLAMP=asymmetric / SC_RADIUS_FLOOR=0.1 set them at load.
  *   key "isect_pull": 1 = sc_isect_bin_count / _sort take the PULL route (every super-tile bucket's sort workgroup
  *                     gathers its own records from a (size class, anchor)-sorted payload: no scatter launch, no records
  *                     buffer) for frames whose key table fits the LDS; 0 = the scatter route (default; the pull route

@@ -94,12 +94,22 @@ def covar_world(quats, scales):
     return S00, S01, S02, S11, S12, S22
 
 
+# The two constants of SURVEY A.1 that differ between upstream gsplat versions (the reference installs an UNPINNED fork,
+# README.md:35): U1 the clamp of x/z, y/z in the EWA Jacobian -- "symmetric" = 1.3 tan(fov/2) on both sides (v1.0-1.3, the
+# default here), "asymmetric" = ((W - cx)/fx + 0.3 tan, cx/fx + 0.3 tan) (v1.4+; identical for a centred principal point);
+# U2 the floor under the radius discriminant -- 0.01 (v1.x, default) or 0.1 (the original Inria rasterizer / early forks).
+# The product selects them with sc_set_option("proj_clamp" / "radius_floor"); every oracle takes the same two arguments.
+PROJ_CLAMPS = ("symmetric", "asymmetric")
+RADIUS_FLOORS = (0.01, 0.1)
+
+
 def fully_fused_projection(means, quats, scales, viewmat, K, width, height,
                            eps2d=0.3, near_plane=0.01, far_plane=1e10,
-                           radius_clip=0.0, calc_compensations=False):
+                           radius_clip=0.0, calc_compensations=False, proj_clamp="symmetric", radius_floor=0.01):
     """One camera.  Returns radii i32[N], means2d f32[N,2], depths f32[N],
     conics f32[N,3], compensations f32[N] (always computed; caller drops it when
     calc_compensations is False).  Culled rows are all-zero."""
+    assert proj_clamp in PROJ_CLAMPS and float(radius_floor) in RADIUS_FLOORS, (proj_clamp, radius_floor)
     means = _f(means)
     V = _f(viewmat)
     K = _f(K)
@@ -136,12 +146,18 @@ def fully_fused_projection(means, quats, scales, viewmat, K, width, height,
         fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
         tanx = F32(0.5) * F32(width) / fx
         tany = F32(0.5) * F32(height) / fy
-        limx = F32(1.3) * tanx
-        limy = F32(1.3) * tany
+        if proj_clamp == "symmetric":
+            limxp = limxn = F32(1.3) * tanx
+            limyp = limyn = F32(1.3) * tany
+        else:
+            limxp = (F32(width) - cx) / fx + F32(0.3) * tanx
+            limxn = cx / fx + F32(0.3) * tanx
+            limyp = (F32(height) - cy) / fy + F32(0.3) * tany
+            limyn = cy / fy + F32(0.3) * tany
         rz = F32(1.0) / z
         rz2 = rz * rz
-        tx = z * np.minimum(limx, np.maximum(-limx, x * rz))
-        ty = z * np.minimum(limy, np.maximum(-limy, y * rz))
+        tx = z * np.minimum(limxp, np.maximum(-limxn, x * rz))
+        ty = z * np.minimum(limyp, np.maximum(-limyn, y * rz))
         ja = fx * rz
         jb = ((-fx) * tx) * rz2
         jc = fy * rz
@@ -170,7 +186,7 @@ def fully_fused_projection(means, quats, scales, viewmat, K, width, height,
         con2 = a1 / det1
 
         bb = F32(0.5) * (a1 + c1)
-        lam = bb + np.sqrt(np.maximum(F32(0.01), bb * bb - det1))
+        lam = bb + np.sqrt(np.maximum(F32(radius_floor), bb * bb - det1))
         radius = np.ceil(F32(3.0) * np.sqrt(lam))
         valid &= ~(radius <= F32(radius_clip))
         valid &= ~np.isnan(radius)
@@ -480,11 +496,13 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
 # --------------------------------------------------------------------------
 def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height,
                  sh_degree, cam_center=None, tile_size=16, near_plane=0.001, far_plane=1000.0,
-                 eps2d=0.3, antialiasing=True, return_unstable=False, unstable_cond=0.0, return_cond_bound=False):
+                 eps2d=0.3, antialiasing=True, return_unstable=False, unstable_cond=0.0, return_cond_bound=False,
+                 proj_clamp="symmetric", radius_floor=0.01):
     """Restates render_kernel_gsplat's forward (one camera).  opacities f32[N,1] or [N]."""
     radii, means2d, depths, conics, comps = fully_fused_projection(
         means, quats, scales, viewmat, K, width, height, eps2d=eps2d,
-        near_plane=near_plane, far_plane=far_plane, calc_compensations=antialiasing)
+        near_plane=near_plane, far_plane=far_plane, calc_compensations=antialiasing, proj_clamp=proj_clamp,
+        radius_floor=radius_floor)
     opac = _f(opacities).reshape(-1)
     if antialiasing:
         opac = opac * comps

@@ -49,17 +49,39 @@ void sco_set_num_threads(int n) {
 }
 
 /* ---- a1 fully_fused_projection (renderer.py:219-234; gsplat_oracle.py:97-190) ---- */
+/* proj_clamp 0 = 1.3 tan(fov/2) on both sides, 1 = ((W - cx)/fx + 0.3 tan, cx/fx + 0.3 tan); radius_floor 0.01 or 0.1:
+ * the two upstream-version-dependent constants (gsplat_oracle.py, PROJ_CLAMPS / RADIUS_FLOORS) */
+void sco_projection_v(const float* means, const float* quats, const float* scales, const float* V /*4x4*/,
+                      const float* K /*3x3*/, int64_t N, int width, int height, float eps2d, float near_plane,
+                      float far_plane, float radius_clip, int proj_clamp, float radius_floor, int32_t* radii,
+                      float* means2d, float* depths, float* conics, float* comps);
 void sco_projection(const float* means, const float* quats, const float* scales, const float* V /*4x4*/,
                     const float* K /*3x3*/, int64_t N, int width, int height, float eps2d, float near_plane,
                     float far_plane, float radius_clip, int32_t* radii, float* means2d, float* depths,
                     float* conics, float* comps) {
+    sco_projection_v(means, quats, scales, V, K, N, width, height, eps2d, near_plane, far_plane, radius_clip, 0, 0.01f, radii,
+                     means2d, depths, conics, comps);
+}
+void sco_projection_v(const float* means, const float* quats, const float* scales, const float* V /*4x4*/,
+                      const float* K /*3x3*/, int64_t N, int width, int height, float eps2d, float near_plane,
+                      float far_plane, float radius_clip, int proj_clamp, float radius_floor, int32_t* radii,
+                      float* means2d, float* depths, float* conics, float* comps) {
     const float W00 = V[0], W01 = V[1], W02 = V[2], tx_ = V[3];
     const float W10 = V[4], W11 = V[5], W12 = V[6], ty_ = V[7];
     const float W20 = V[8], W21 = V[9], W22 = V[10], tz_ = V[11];
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const float tanx = 0.5f * (float)width / fx, tany = 0.5f * (float)height / fy;
-    const float limx = 1.3f * tanx, limy = 1.3f * tany;
     const float Wf = (float)width, Hf = (float)height;
+    float limxp, limxn, limyp, limyn;
+    if (proj_clamp == 0) {
+        limxp = limxn = 1.3f * tanx;
+        limyp = limyn = 1.3f * tany;
+    } else {
+        limxp = (Wf - cx) / fx + 0.3f * tanx;
+        limxn = cx / fx + 0.3f * tanx;
+        limyp = (Hf - cy) / fy + 0.3f * tany;
+        limyn = cy / fy + 0.3f * tany;
+    }
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
@@ -94,8 +116,8 @@ void sco_projection(const float* means, const float* quats, const float* scales,
         const float c02 = dot3(T00, W20, T01, W21, T02, W22), c11 = dot3(T10, W10, T11, W11, T12, W12);
         const float c12 = dot3(T10, W20, T11, W21, T12, W22), c22 = dot3(T20, W20, T21, W21, T22, W22);
         const float rz = 1.0f / z, rz2 = rz * rz;
-        const float tx = z * fminf(limx, fmaxf(-limx, x * rz));
-        const float ty = z * fminf(limy, fmaxf(-limy, y * rz));
+        const float tx = z * fminf(limxp, fmaxf(-limxn, x * rz));
+        const float ty = z * fminf(limyp, fmaxf(-limyn, y * rz));
         const float ja = fx * rz, jb = ((-fx) * tx) * rz2, jc = fy * rz, jd = ((-fy) * ty) * rz2;
         const float u0 = ja * c00 + jb * c02, u1 = ja * c01 + jb * c12, u2 = ja * c02 + jb * c22;
         const float v1 = jc * c11 + jd * c12, v2 = jc * c12 + jd * c22;
@@ -112,7 +134,7 @@ void sco_projection(const float* means, const float* quats, const float* scales,
         const float con0 = c1 / det1, con1 = (-b) / det1, con2 = a1 / det1;
         const float bb = 0.5f * (a1 + c1);
         const float disc = bb * bb - det1;
-        const float lam = bb + sqrtf(disc != disc ? disc : (disc > 0.01f ? disc : 0.01f));
+        const float lam = bb + sqrtf(disc != disc ? disc : (disc > radius_floor ? disc : radius_floor));
         const float radius = ceilf(3.0f * sqrtf(lam));
         valid &= !(radius <= radius_clip);
         valid &= !(radius != radius);

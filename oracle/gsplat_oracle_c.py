@@ -32,6 +32,8 @@ def load(build_if_missing=True):
     lib.sco_set_num_threads.argtypes = [i32]
     lib.sco_projection.argtypes = [P, P, P, P, P, i64, i32, i32, f32, f32, f32, f32, P, P, P, P, P]
     lib.sco_projection.restype = None
+    lib.sco_projection_v.argtypes = [P, P, P, P, P, i64, i32, i32, f32, f32, f32, f32, i32, f32, P, P, P, P, P]
+    lib.sco_projection_v.restype = None
     lib.sco_isect_count.argtypes = [P, P, i64, i32, i32, i32, P]
     lib.sco_isect_count.restype = i64
     lib.sco_isect_emit_sort.argtypes = [P, P, P, i32, i64, i32, i32, i32, P, i64, i32, P, P, P]
@@ -63,7 +65,8 @@ def _p(a):
 
 
 def fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01,
-                           far_plane=1e10, radius_clip=0.0):
+                           far_plane=1e10, radius_clip=0.0, proj_clamp="symmetric", radius_floor=0.01):
+    assert proj_clamp in ("symmetric", "asymmetric") and float(radius_floor) in (0.01, 0.1), (proj_clamp, radius_floor)
     lib = load()
     means, quats, scales = _c(means, np.float32), _c(quats, np.float32), _c(scales, np.float32)
     V, K = _c(viewmat, np.float32), _c(K, np.float32)
@@ -71,9 +74,9 @@ def fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2
     radii = np.empty(N, np.int32)
     m2, d = np.empty((N, 2), np.float32), np.empty(N, np.float32)
     con, comp = np.empty((N, 3), np.float32), np.empty(N, np.float32)
-    lib.sco_projection(_p(means), _p(quats), _p(scales), _p(V), _p(K), N, int(width), int(height), float(eps2d),
-                       float(near_plane), float(far_plane), float(radius_clip), _p(radii), _p(m2), _p(d), _p(con),
-                       _p(comp))
+    lib.sco_projection_v(_p(means), _p(quats), _p(scales), _p(V), _p(K), N, int(width), int(height), float(eps2d),
+                         float(near_plane), float(far_plane), float(radius_clip), 0 if proj_clamp == "symmetric" else 1,
+                         float(radius_floor), _p(radii), _p(m2), _p(d), _p(con), _p(comp))
     return radii, m2, d, con, comp
 
 
@@ -137,10 +140,11 @@ def rasterize_to_pixels(means2d, conics, colors, opacities, image_width, image_h
 
 def render_frame(means, quats, scales, opacities, sh_coeffs, viewmat, K, width, height, sh_degree, cam_center=None,
                  tile_size=16, near_plane=0.001, far_plane=1000.0, eps2d=0.3, antialiasing=True,
-                 return_unstable=False, unstable_cond=0.0, return_cond_bound=False):
+                 return_unstable=False, unstable_cond=0.0, return_cond_bound=False, proj_clamp="symmetric", radius_floor=0.01):
     """The caller's sequence (renderer.py:186-302), same outputs as gsplat_oracle.render_frame."""
     radii, m2, d, con, comp = fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2d=eps2d,
-                                                     near_plane=near_plane, far_plane=far_plane)
+                                                     near_plane=near_plane, far_plane=far_plane, proj_clamp=proj_clamp,
+                                                     radius_floor=radius_floor)
     opac = np.asarray(opacities, np.float32).reshape(-1)
     if antialiasing:
         opac = opac * comp

@@ -32,8 +32,10 @@ def quat_scale_to_covar(quats, scales):
 
 
 def fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2d=0.3,
-                           near_plane=0.01, far_plane=1e10, radius_clip=0.0):
-    """Returns radii (long), means2d, depths, conics, compensations; culled rows zero."""
+                           near_plane=0.01, far_plane=1e10, radius_clip=0.0, proj_clamp="symmetric", radius_floor=0.01):
+    """Returns radii (long), means2d, depths, conics, compensations; culled rows zero.
+    proj_clamp / radius_floor: the upstream-version-dependent constants (gsplat_oracle.py, PROJ_CLAMPS / RADIUS_FLOORS)."""
+    assert proj_clamp in ("symmetric", "asymmetric") and float(radius_floor) in (0.01, 0.1), (proj_clamp, radius_floor)
     Wm = viewmat[:3, :3]
     t = viewmat[:3, 3]
     pc = means @ Wm.T + t
@@ -42,12 +44,17 @@ def fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2
     cov = quat_scale_to_covar(quats, scales)
     covc = Wm @ cov @ Wm.T
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
-    limx = 1.3 * 0.5 * width / fx
-    limy = 1.3 * 0.5 * height / fy
+    tanx, tany = 0.5 * width / fx, 0.5 * height / fy
+    if proj_clamp == "symmetric":
+        limxp = limxn = 1.3 * tanx
+        limyp = limyn = 1.3 * tany
+    else:
+        limxp, limxn = (width - cx) / fx + 0.3 * tanx, cx / fx + 0.3 * tanx
+        limyp, limyn = (height - cy) / fy + 0.3 * tany, cy / fy + 0.3 * tany
     zs = torch.where(valid, z, torch.ones_like(z))
     rz = 1.0 / zs
-    tx = zs * torch.clamp(x * rz, -limx, limx)
-    ty = zs * torch.clamp(y * rz, -limy, limy)
+    tx = zs * torch.minimum(torch.maximum(x * rz, -limxn), limxp)
+    ty = zs * torch.minimum(torch.maximum(y * rz, -limyn), limyp)
     zero = torch.zeros_like(z)
     J = torch.stack([fx * rz, zero, -fx * tx * rz * rz,
                      zero, fy * rz, -fy * ty * rz * rz], dim=-1).reshape(-1, 2, 3)
@@ -63,7 +70,7 @@ def fully_fused_projection(means, quats, scales, viewmat, K, width, height, eps2
     comp = torch.sqrt(torch.clamp(det0 / det1s, min=0.0))
     conics = torch.stack([c1 / det1s, -b / det1s, a1 / det1s], dim=-1)
     bb = 0.5 * (a1 + c1)
-    lam = bb + torch.sqrt(torch.clamp(bb * bb - det1s, min=0.01))
+    lam = bb + torch.sqrt(torch.clamp(bb * bb - det1s, min=float(radius_floor)))
     radius = torch.ceil(3.0 * torch.sqrt(lam)).detach()
     valid = valid & ~(radius <= radius_clip)
     valid = valid & ~((m2x + radius <= 0) | (m2x - radius >= width) |

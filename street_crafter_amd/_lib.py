@@ -135,6 +135,17 @@ def _load_locked():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # the upstream-version-dependent constants of fully_fused_projection (include/street_crafter_amd.h, sc_set_option
+    # "proj_clamp" / "radius_floor"), for a user who holds the real gsplat fork and need not touch code to match it
+    env_c, env_f = os.environ.get("SC_PROJ_CLAMP"), os.environ.get("SC_RADIUS_FLOOR")
+    if env_c:
+        if env_c not in ("symmetric", "asymmetric"):
+            raise ValueError(f"SC_PROJ_CLAMP must be symmetric or asymmetric, got {env_c!r}")
+        lib.sc_set_option(b"proj_clamp", 1 if env_c == "asymmetric" else 0)
+    if env_f:
+        if float(env_f) not in (0.01, 0.1):
+            raise ValueError(f"SC_RADIUS_FLOOR must be 0.01 or 0.1, got {env_f!r}")
+        lib.sc_set_option(b"radius_floor", 1 if float(env_f) == 0.1 else 0)
     return lib
 
 
@@ -190,6 +201,27 @@ def check(code: int, what: str):
     if code != 0:
         msg = load().sc_error_string(int(code)).decode()
         raise RuntimeError(f"{what} failed: {msg} (code {code})")
+
+
+def set_projection_variant(proj_clamp: str = None, radius_floor: float = None):
+    """Selects the upstream-version-dependent constants of fully_fused_projection (the reference installs
+    an unpinned gsplat fork, README.md:35): proj_clamp "symmetric" (1.3 tan(fov/2), gsplat v1.0-1.3, default) or "asymmetric"
+    ((W - cx)/fx + 0.3 tan, cx/fx + 0.3 tan: v1.4+); radius_floor 0.01 (v1.x, default) or 0.1 (Inria / early forks).  None
+    leaves a setting as it is.  Returns the previous (proj_clamp, radius_floor)."""
+    lib = load()
+    cur_c = lib.sc_set_option(b"proj_clamp", 0)
+    lib.sc_set_option(b"proj_clamp", cur_c)
+    cur_f = lib.sc_set_option(b"radius_floor", 0)
+    lib.sc_set_option(b"radius_floor", cur_f)
+    if proj_clamp is not None:
+        if proj_clamp not in ("symmetric", "asymmetric"):
+            raise ValueError(f"proj_clamp must be 'symmetric' or 'asymmetric', got {proj_clamp!r}")
+        lib.sc_set_option(b"proj_clamp", 1 if proj_clamp == "asymmetric" else 0)
+    if radius_floor is not None:
+        if float(radius_floor) not in (0.01, 0.1):
+            raise ValueError(f"radius_floor must be 0.01 or 0.1, got {radius_floor!r}")
+        lib.sc_set_option(b"radius_floor", 1 if float(radius_floor) == 0.1 else 0)
+    return ("asymmetric" if cur_c else "symmetric", 0.1 if cur_f else 0.01)
 
 
 def set_option(key: str, value: int) -> int:

@@ -32,6 +32,8 @@ extern "C" const char* sc_error_string(int code) {
 #ifdef SC_DIAG
 int g_sc_debug[4] = {0, 0, 0, 0};       // diagnostic build only (sc_common.h)
 #endif
+int g_sc_proj_clamp = 0;        // sc_set_option "proj_clamp" (projection_common.h)
+int g_sc_radius_floor = 0;      // sc_set_option "radius_floor"
 
 // Host-side wait for the sequence number that center_scatter_kernel publishes behind the frame's sizes
 // (host-mapped pinned memory, include/street_crafter_amd.h sc_isect_bin_count).  A plain spin in C: a Python host
@@ -119,6 +121,18 @@ extern "C" int sc_set_option(const char* key, int value) {
         if (value < 0 || value > 100) return SC_EINVAL;
         const int prev = g_sc_raster_split;
         g_sc_raster_split = value;
+        return prev;
+    }
+    if (strcmp(key, "proj_clamp") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_proj_clamp;
+        g_sc_proj_clamp = value;
+        return prev;
+    }
+    if (strcmp(key, "radius_floor") == 0) {
+        if (value < 0 || value > 1) return SC_EINVAL;
+        const int prev = g_sc_radius_floor;
+        g_sc_radius_floor = value;
         return prev;
     }
     if (strcmp(key, "isect_pull") == 0) {

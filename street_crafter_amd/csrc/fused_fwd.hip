@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void projection_sh_fwd_kernel(
     const float* __restrict__ opacities, const float* __restrict__ coeffs,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, const float* __restrict__ campos,
     int N, int K, int width, int height, float eps2d, float near_plane, float far_plane,
-    float radius_clip, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
+    float radius_clip, ProjOpt opt, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
     float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ opac_out,
     float* __restrict__ colors4, float4* __restrict__ records) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void projection_sh_fwd_kernel(
     const Cam c = load_cam(viewmats + cam * 16, Ks + cam * 9);
     const size_t o = (size_t)cam * N + n;
     const ProjOut p = project_one(c, means, quats, scales, n, width, height, eps2d, near_plane, far_plane,
-                                  radius_clip);
+                                  radius_clip, opt);
     radii[o] = p.rad_i;
     *reinterpret_cast<float2*>(means2d + o * 2) = make_float2(p.m2x, p.m2y);
     depths[o] = p.depth;
@@ -125,7 +125,7 @@ extern "C" int sc_projection_sh_fwd(const float* means, const float* quats, cons
 #define SC_LAUNCH_FUSED(DEG)                                                                                 \
     hipLaunchKernelGGL(projection_sh_fwd_kernel<DEG>, grid, dim3(256), 0, sc_s(stream), means, quats, scales,  \
                        opacities, sh_coeffs, viewmats, Ks, camera_centers, N, K, width, height, eps2d,        \
-                       near_plane, far_plane, radius_clip, antialiased, radii, means2d, depths, conics,        \
+                       near_plane, far_plane, radius_clip, sc_proj_opt(), antialiased, radii, means2d, depths, conics, \
                        opacities_out, colors4, reinterpret_cast<float4*>(records))
     switch (sh_degree) {
         case 0: SC_LAUNCH_FUSED(0); break;

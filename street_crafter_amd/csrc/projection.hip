@@ -15,7 +15,7 @@ namespace {
 __global__ __launch_bounds__(256) void projection_fwd_kernel(
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int N, int width, int height,
-    float eps2d, float near_plane, float far_plane, float radius_clip,
+    float eps2d, float near_plane, float far_plane, float radius_clip, ProjOpt opt,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ depths,
     float* __restrict__ conics, float* __restrict__ comps) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
     const size_t o = (size_t)cam * N + n;
 
     const ProjOut p = project_one(c, means, quats, scales, n, width, height, eps2d, near_plane, far_plane,
-                                  radius_clip);
+                                  radius_clip, opt);
     radii[o] = p.rad_i;
     *reinterpret_cast<float2*>(means2d + o * 2) = make_float2(p.m2x, p.m2y);
     depths[o] = p.depth;
@@ -48,7 +48,7 @@ namespace {
 __global__ __launch_bounds__(256) void projection_bwd_kernel(
     const float* __restrict__ means, const float* __restrict__ quats, const float* __restrict__ scales,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int C, int N, int width,
-    int height, float eps2d, const int32_t* __restrict__ radii, const float* __restrict__ conics,
+    int height, float eps2d, ProjOpt opt, const int32_t* __restrict__ radii, const float* __restrict__ conics,
     const float* __restrict__ comps, const float* __restrict__ v_means2d,
     const float* __restrict__ v_depths, const float* __restrict__ v_conics,
     const float* __restrict__ v_comps, float* __restrict__ v_means, float* __restrict__ v_quats,
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(256) void projection_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < 3; ++j) Sc[i][j] = T[i][0] * Wm[j][0] + T[i][1] * Wm[j][1] + T[i][2] * Wm[j][2];
 
-        const float limx = 1.3f * 0.5f * (float)width / fx, limy = 1.3f * 0.5f * (float)height / fy;
+        const ProjLim lim = proj_limits(opt, fx, fy, K[2], K[5], width, height);
         const float rz = 1.f / z, rz2 = rz * rz;
         const float xr = x * rz, yr = y * rz;
-        const bool clx = (xr < -limx) || (xr > limx);
-        const bool cly = (yr < -limy) || (yr > limy);
-        const float tx = z * fminf(limx, fmaxf(-limx, xr));
-        const float ty = z * fminf(limy, fmaxf(-limy, yr));
+        const bool clx = (xr < -lim.xn) || (xr > lim.xp);
+        const bool cly = (yr < -lim.yn) || (yr > lim.yp);
+        const float tx = z * fminf(lim.xp, fmaxf(-lim.xn, xr));
+        const float ty = z * fminf(lim.yp, fmaxf(-lim.yn, yr));
         // J = [[ja,0,jb],[0,jc,jd]]
         const float ja = fx * rz, jb = -fx * tx * rz2, jc = fy * rz, jd = -fy * ty * rz2;
         // cov2d = J Sc J^T
@@ -245,7 +245,7 @@ extern "C" int sc_projection_fwd(const float* means, const float* quats, const f
     if (C > 65535) return SC_EINVAL;
     dim3 grid((N + 255) / 256, C);
     hipLaunchKernelGGL(projection_fwd_kernel, grid, dim3(256), 0, sc_s(stream), means, quats, scales,
-                       viewmats, Ks, N, width, height, eps2d, near_plane, far_plane, radius_clip,
+                       viewmats, Ks, N, width, height, eps2d, near_plane, far_plane, radius_clip, sc_proj_opt(),
                        radii, means2d, depths, conics, compensations);
     SC_LAUNCH_CHECK();
     return SC_OK;
@@ -264,7 +264,7 @@ extern "C" int sc_projection_bwd(const float* means, const float* quats, const f
         !v_depths || !v_conics || !v_means || !v_quats || !v_scales)
         return SC_EINVAL;
     hipLaunchKernelGGL(projection_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, sc_s(stream),
-                       means, quats, scales, viewmats, Ks, C, N, width, height, eps2d, radii, conics,
+                       means, quats, scales, viewmats, Ks, C, N, width, height, eps2d, sc_proj_opt(), radii, conics,
                        compensations, v_means2d, v_depths, v_conics, v_compensations, v_means,
                        v_quats, v_scales);
     SC_LAUNCH_CHECK();

@@ -6,6 +6,9 @@
 
 #pragma clang fp contract(off)
 
+struct ProjOpt { int clamp; float radius_floor; };
+extern int g_sc_proj_clamp, g_sc_radius_floor;       // sc_set_option "proj_clamp" / "radius_floor" (capi.hip)
+
 namespace {
 
 __device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
@@ -26,6 +29,29 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float
     return c;
 }
 
+// The two constants of SURVEY A.1 that differ between upstream gsplat versions (the reference installs an unpinned fork,
+// README.md:35), selectable at run time: sc_set_option("proj_clamp") 0 = x/z, y/z clamped to +-1.3 tan(fov/2) (v1.0-1.3,
+// default), 1 = to [-(cx/fx + 0.3 tan), (W - cx)/fx + 0.3 tan] (v1.4+); sc_set_option("radius_floor") 0 = 0.01 (v1.x,
+// default), 1 = 0.1 (the original Inria rasterizer).  oracle/gsplat_oracle.py takes the same two arguments.
+static inline ProjOpt sc_proj_opt() { return ProjOpt{g_sc_proj_clamp, g_sc_radius_floor ? 0.1f : 0.01f}; }
+
+struct ProjLim { float xp, xn, yp, yn; };       // tan-space limits: x/z in [-xn, xp], y/z in [-yn, yp]
+__device__ __forceinline__ ProjLim proj_limits(const ProjOpt& opt, float fx, float fy, float cx, float cy, int width, int height) {
+    const float tanx = 0.5f * (float)width / fx;
+    const float tany = 0.5f * (float)height / fy;
+    ProjLim l;
+    if (opt.clamp == 0) {
+        l.xp = l.xn = 1.3f * tanx;
+        l.yp = l.yn = 1.3f * tany;
+    } else {
+        l.xp = ((float)width - cx) / fx + 0.3f * tanx;
+        l.xn = cx / fx + 0.3f * tanx;
+        l.yp = ((float)height - cy) / fy + 0.3f * tany;
+        l.yn = cy / fy + 0.3f * tany;
+    }
+    return l;
+}
+
 struct ProjOut {
     int rad_i;
     float m2x, m2y, con0, con1, con2, comp, depth;
@@ -35,7 +61,7 @@ __device__ __forceinline__ ProjOut project_one(const Cam& c, const float* __rest
                                                const float* __restrict__ quats,
                                                const float* __restrict__ scales, int n, int width, int height,
                                                float eps2d, float near_plane, float far_plane,
-                                               float radius_clip) {
+                                               float radius_clip, const ProjOpt& opt) {
     const float mx = means[n * 3 + 0], my = means[n * 3 + 1], mz = means[n * 3 + 2];
     const float x = dot3(c.W00, mx, c.W01, my, c.W02, mz) + c.tx;
     const float y = dot3(c.W10, mx, c.W11, my, c.W12, mz) + c.ty;
@@ -84,13 +110,11 @@ __device__ __forceinline__ ProjOut project_one(const Cam& c, const float* __rest
         const float c12 = dot3(T10, c.W20, T11, c.W21, T12, c.W22);
         const float c22 = dot3(T20, c.W20, T21, c.W21, T22, c.W22);
 
-        const float tanx = 0.5f * (float)width / c.fx;
-        const float tany = 0.5f * (float)height / c.fy;
-        const float limx = 1.3f * tanx, limy = 1.3f * tany;
+        const ProjLim lim = proj_limits(opt, c.fx, c.fy, c.cx, c.cy, width, height);
         const float rz = 1.0f / z;
         const float rz2 = rz * rz;
-        const float tx = z * fminf(limx, fmaxf(-limx, x * rz));
-        const float ty = z * fminf(limy, fmaxf(-limy, y * rz));
+        const float tx = z * fminf(lim.xp, fmaxf(-lim.xn, x * rz));
+        const float ty = z * fminf(lim.yp, fmaxf(-lim.yn, y * rz));
         const float ja = c.fx * rz;
         const float jb = ((-c.fx) * tx) * rz2;
         const float jc = c.fy * rz;
@@ -116,7 +140,7 @@ __device__ __forceinline__ ProjOut project_one(const Cam& c, const float* __rest
         con1 = (-b) / det1;
         con2 = a1 / det1;
         const float bb = 0.5f * (a1 + c1);
-        const float lam = bb + sqrtf(fmaxf(0.01f, bb * bb - det1));
+        const float lam = bb + sqrtf(fmaxf(opt.radius_floor, bb * bb - det1));
         const float radius = ceilf(3.0f * sqrtf(lam));
         valid = valid && (radius > radius_clip);  // false for NaN
         const float Wf = (float)width, Hf = (float)height;

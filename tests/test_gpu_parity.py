@@ -818,6 +818,62 @@ def test_projection_backward_one_output_at_a_time(ops, golden_dir, which):
     print("worst error / tolerance:", {k: round(v, 3) for k, v in worst.items()})
 
 
+@pytest.mark.parametrize("clamp,floor", [("symmetric", 0.01), ("asymmetric", 0.01), ("symmetric", 0.1), ("asymmetric", 0.1)])
+def test_projection_variants_selected_at_run_time(ops, golden_dir, clamp, floor):
+    """sc_set_option("proj_clamp" / "radius_floor") (_lib.set_projection_variant; SURVEY A.1 U1 / U2: the reference installs
+    an unpinned gsplat fork, README.md:35): under every pair the forward is bit-identical to tests/golden/proj_variants.npz
+    (numpy oracle, off-centre principal point), the fused rasterization() forward projects the same way, and the backward
+    agrees with float64 autograd of the torch oracle under the same pair."""
+    from street_crafter_amd import _lib
+    mg = _make_golden()
+    g = _load(golden_dir, "proj_variants.npz")
+    tag = f"{clamp}_{floor}"
+    W, H, near, far = int(g["width"]), int(g["height"]), float(g["near"]), float(g["far"])
+    means, quats, scales = _t(g["means"]), _t(g["quats"]), _t(g["scales"])
+    V, K = _t(g["viewmat"])[None], _t(g["K"])[None]
+    sh = torch.rand(means.shape[0], 4, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    opac = torch.rand(means.shape[0], generator=torch.Generator().manual_seed(2)).to(DEV)
+    prev = _lib.set_projection_variant(clamp, floor)
+    try:
+        assert _lib.set_projection_variant() == (clamp, floor)
+        with torch.no_grad():
+            out = ops.fully_fused_projection(means, None, quats, scales, V, K, W, H, near_plane=near, far_plane=far,
+                                             calc_compensations=True)
+            for t, name in zip(out, ("radii", "means2d", "depths", "conics", "compensations")):
+                np.testing.assert_array_equal(_np(t)[0].view(np.uint32), g[f"{tag}_{name}"].view(np.uint32), err_msg=name)
+            rc, ra, meta = ops.rasterization(means, quats, scales, opac, sh, V, K, W, H, near_plane=near, far_plane=far,
+                                             sh_degree=1, render_mode="RGB+ED", rasterize_mode="antialiased")
+            assert meta["fused"]
+            np.testing.assert_array_equal(_np(meta["radii"])[0], g[f"{tag}_radii"])
+            np.testing.assert_array_equal(_np(meta["means2d"])[0].view(np.uint32), g[f"{tag}_means2d"].view(np.uint32))
+            np.testing.assert_array_equal(_np(meta["conics"])[0].view(np.uint32), g[f"{tag}_conics"].view(np.uint32))
+        # backward on a well-conditioned case with clamped Jacobians, seen through the same off-centre camera
+        means, quats, scales, bcam = mg.projection_bwd_case("clamped")      # (float64 autograd on the box: inputs need not be portable)
+        Kb = bcam.K.clone()
+        Kb[0, 2], Kb[1, 2] = 0.4 * 320, 0.58 * 200
+        rng = np.random.default_rng(5)
+        wts = [rng.normal(size=s_).astype(np.float32) for s_ in ((360, 2), (360,), (360, 3), (360,))]
+        leaves = [t.clone().to(DEV).requires_grad_(True) for t in (means, quats, scales)]
+        radii, m2, d, con, comp = ops.fully_fused_projection(leaves[0], None, leaves[1], leaves[2], bcam.viewmat.to(DEV)[None],
+                                                             Kb.to(DEV)[None], 320, 200, near_plane=0.001, far_plane=1000.0,
+                                                             calc_compensations=True)
+        ((m2[0] * _t(wts[0])).sum() + (d[0] * _t(wts[1])).sum() + (con[0] * _t(wts[2])).sum()
+         + (comp[0] * _t(wts[3])).sum()).backward()
+        ref = [t.clone().double().requires_grad_(True) for t in (means, quats, scales)]
+        rr, m2r, dr, conr, compr = OT.fully_fused_projection(ref[0], ref[1], ref[2], bcam.viewmat.double(), Kb.double(), 320, 200,
+                                                             near_plane=0.001, far_plane=1000.0, proj_clamp=clamp,
+                                                             radius_floor=floor)
+        ((m2r * torch.from_numpy(wts[0]).double()).sum() + (dr * torch.from_numpy(wts[1]).double()).sum()
+         + (conr * torch.from_numpy(wts[2]).double()).sum() + (compr * torch.from_numpy(wts[3]).double()).sum()).backward()
+        np.testing.assert_array_equal(_np(radii)[0] > 0, rr.numpy() > 0)
+        assert int((_np(radii)[0] > 0).sum()) > 100
+        for h_, r_, name in zip(leaves, ref, ("means", "quats", "scales")):
+            assert _rel_err(_np(h_.grad), r_.grad.numpy()) < 2e-3, name
+    finally:
+        _lib.set_projection_variant(*prev)
+    assert _lib.set_projection_variant() == prev
+
+
 def test_backward_kernels_reproduce_the_committed_gradients(ops, golden_dir):
     """Rasterize and SH backward against tests/golden/bwd_small.npz (float64 autograd of the oracle, committed):
     the same bars as the recomputing tests below, without running the oracle on the box."""

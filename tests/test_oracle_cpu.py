@@ -425,3 +425,38 @@ def test_float64_blend_enumerates_unresolvable_decisions():
     assert len(clear) == 1 and abs(clear[0].alpha - 0.5) < 1e-12 and np.allclose(clear[0].color, [0.0, 0.5, 0.0])
     c32, a32 = B.blend_pixel_pinned_fp32(8.5, 8.5, [1], m2, cn, co, op)
     assert abs(float(a32) - 0.5) < 1e-6 and np.allclose(c32, [0.0, 0.5, 0.0], atol=1e-6)
+
+
+# ---- the upstream-version-dependent constants of the projection -----------------------------------
+@pytest.mark.parametrize("clamp", O.PROJ_CLAMPS)
+@pytest.mark.parametrize("floor", O.RADIUS_FLOORS)
+def test_projection_variants_fixture_and_oracles_agree(golden_dir, clamp, floor):
+    """tests/golden/proj_variants.npz: the numpy oracle still produces the committed outputs of every (Jacobian clamp,
+    radius floor) pair; the C restatement is bit-identical under each; the float64 torch restatement (the gradient oracle)
+    agrees to rounding.  The two clamps differ only for an off-centre principal point; the floor only changes radii."""
+    import torch
+    from oracle import gsplat_oracle_c as OC
+    g = _load(golden_dir, "proj_variants.npz")
+    W, H = int(g["width"]), int(g["height"])
+    a = (g["means"], g["quats"], g["scales"], g["viewmat"], g["K"], W, H)
+    kw = dict(near_plane=float(g["near"]), far_plane=float(g["far"]), proj_clamp=clamp, radius_floor=floor)
+    out = O.fully_fused_projection(*a, **kw)
+    outc = OC.fully_fused_projection(*a, **kw)
+    tag = f"{clamp}_{floor}"
+    for arr, arrc, name in zip(out, outc, ("radii", "means2d", "depths", "conics", "compensations")):
+        np.testing.assert_array_equal(arr.view(np.uint32), g[f"{tag}_{name}"].view(np.uint32), err_msg=name)
+        np.testing.assert_array_equal(arrc.view(np.uint32), arr.view(np.uint32), err_msg="C oracle " + name)
+    rt, m2t, dt, cont, compt = OT.fully_fused_projection(*[torch.from_numpy(x).double() for x in a[:5]], W, H, **kw)
+    same = out[0] == rt.numpy()
+    assert same.mean() > 0.995
+    vis = (out[0] > 0) & same
+    # (edge cases: needles and enormous splats are ill-conditioned in fp32; the well-conditioned majority must agree)
+    close = np.isclose(out[3][vis], cont.numpy()[vis], rtol=5e-3, atol=1e-6).all(axis=1)
+    assert close.mean() > 0.9
+    base = _load(golden_dir, "proj_variants.npz")
+    if floor == 0.1:        # the floor moves radii only
+        for name in ("means2d", "depths", "conics", "compensations"):
+            keep = (g[f"{tag}_radii"] > 0) & (base[f"{clamp}_0.01_radii"] > 0)
+            np.testing.assert_array_equal(g[f"{tag}_{name}"][keep], base[f"{clamp}_0.01_{name}"][keep])
+        assert (g[f"{tag}_radii"] >= base[f"{clamp}_0.01_radii"]).all()
+

@@ -67,7 +67,36 @@ def oracle_vectors():
                         width=cam.width, height=cam.height, near=cam.znear, far=cam.zfar, radii=radii,
                         means2d=m2, depths=dep, conics=con, compensations=comp)
 
+    projection_variant_vectors()
+
     # (2)+(3) small full pipeline: 128 x 96 image (8 x 6 tiles), 3000 Gaussians, 4 channels
+    _oracle_vectors_rest(O, KO, make_camera, make_scene)
+
+
+def projection_variant_vectors():
+    """(1b) the projection under the upstream-version-dependent constants (oracle/gsplat_oracle.py
+    PROJ_CLAMPS / RADIUS_FLOORS): edge cases seen through a camera whose principal point is OFF centre (the two clamps
+    agree for a centred one); outputs per variant -> tests/golden/proj_variants.npz"""
+    from oracle import gsplat_oracle as O
+    sc, cam = projection_variant_case()
+    var = {}
+    for clamp in O.PROJ_CLAMPS:
+        for floor in O.RADIUS_FLOORS:
+            r, m2, dep, con, comp = O.fully_fused_projection(
+                sc.means.numpy(), sc.quats.numpy(), sc.scales.numpy(), cam.viewmat.numpy(), cam.K.numpy(), cam.width,
+                cam.height, near_plane=cam.znear, far_plane=cam.zfar, proj_clamp=clamp, radius_floor=floor)
+            tag = f"{clamp}_{floor}"
+            var.update({f"{tag}_radii": r, f"{tag}_means2d": m2, f"{tag}_depths": dep, f"{tag}_conics": con,
+                        f"{tag}_compensations": comp})
+    assert not np.array_equal(var["symmetric_0.01_conics"], var["asymmetric_0.01_conics"])
+    assert not np.array_equal(var["symmetric_0.01_radii"], var["symmetric_0.1_radii"])
+    # (inputs stored as well: torch's CPU normal generator is not bit-identical across hosts)
+    np.savez_compressed(os.path.join(GOLD, "proj_variants.npz"), means=sc.means.numpy(), quats=sc.quats.numpy(),
+                        scales=sc.scales.numpy(), viewmat=cam.viewmat.numpy(), K=cam.K.numpy(), width=cam.width,
+                        height=cam.height, near=cam.znear, far=cam.zfar, **var)
+
+
+def _oracle_vectors_rest(O, KO, make_camera, make_scene):
     cam = make_camera(width=128, height=96, fx=140.0, fy=140.0)
     sc = make_scene(3000, sh_degree=1, seed=5, x_span=0.6, y_span=0.45, z_range=(1.0, 30.0),
                     scale_range=(0.01, 0.4))
@@ -90,6 +119,16 @@ def oracle_vectors():
     np.savez_compressed(os.path.join(GOLD, "knn_small.npz"), pts=pts, out=KO.dist_cuda2(pts), dup=dup,
                         out_dup=KO.dist_cuda2(dup), line=line, out_line=KO.dist_cuda2(line),
                         tiny=pts[:3], out_tiny=KO.dist_cuda2(pts[:3]))
+
+
+def projection_variant_case():
+    """Inputs of tests/golden/proj_variants.npz."""
+    from street_crafter_amd.scenes import make_camera, make_edge_case_scene
+    sc = make_edge_case_scene(1536, seed=23)
+    cam = make_camera(960, 600, 520.0, 540.0, yaw=0.05, shift=(0.1, 0.05, -0.2))
+    cam.K[0, 2] = 0.42 * 960          # principal point off centre: the asymmetric clamp's limits differ left / right
+    cam.K[1, 2] = 0.57 * 600
+    return sc, cam
 
 
 PROJ_GROUPS = ("means2d_x", "means2d_y", "depths", "conic_a", "conic_b", "conic_c", "compensation")
