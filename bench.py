@@ -381,9 +381,15 @@ def run_rank(args):
               f"(or without a launcher: bench.py starts its own ranks)", file=sys.stderr)
         sys.exit(2)
     selftest = args.selftest_cpu
+    placement = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")      # (RCCL states its version once, on stderr; the line carries it too)
+        if not selftest and not args.oversubscribe:
+            # before the first GPU call: this rank's host threads onto the CPUs of its GPU's NUMA node (dist.bind_rank)
+            from street_crafter_amd.dist import bind_rank
+            placement = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if selftest:
         dev = torch.device("cpu")
         if world > 1:
@@ -555,6 +561,11 @@ def run_rank(args):
                 expect = (7 * (w_ + (r_ + args.warmup) * world)) % 251
                 assert int(f[0, 0, 0]) == expect and int(f.min()) == int(f.max()), (k, int(f[0, 0, 0]), expect)
 
+    placements = None
+    if world > 1 and not selftest:
+        placements = [None] * world
+        dist.all_gather_object(placements, dict(placement or {}, rank=rank, device=str(dev),
+                                                pci_of_device=getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)))
     gathered_ok = None
     if rank == 0 and world > 1 and not selftest:
         # every rank's first timed frame, as it arrived through the gather, against a local re-render of that frame
@@ -572,6 +583,13 @@ def run_rank(args):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "per_rank_frames_per_s": per_rank_fps, "gathered_frames_match_local_render": gathered_ok,
+            "ranks": None if placements is None else {
+                "placement": placements,
+                "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if args.backend == "nccl" else None,
+                "devices_visible_per_rank": "all (torch.cuda.set_device(LOCAL_RANK)): RCCL's xGMI transport maps peer buffers "
+                                            "through hipIpc / peer access, which needs the peers enumerated in the process",
+                "what": "dist.bind_rank before the first GPU call: host threads of every rank on the CPUs local to its GPU's "
+                        "NUMA node (an equal share per rank on that node), torch intra-op threads capped; SC_BIND_CPUS=0 = off"},
             "gather": {"frames_per_collective": gatherer.batch, "collectives": gatherer.stats["gathers"],
                        "bytes_into_root_per_collective": gatherer.stats["bytes_per_gather"],
                        "host_ms_issuing_per_collective": (gatherer.stats["host_s_in_gather_calls"] * 1e3 /

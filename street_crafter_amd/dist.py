@@ -368,6 +368,110 @@ def render_sharded(n_frames: int, render_frame: Callable[..., torch.Tensor], dst
     return frames if rank == dst else None
 
 
+# ---- per-rank host placement (one process per GPU; render.py:64-70's frames are sharded one per rank) -------------------
+def _parse_cpulist(text: str) -> List[int]:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_host_topology(sysfs: str = "/sys") -> List[Dict]:
+    """The GPUs of this machine in HIP's default enumeration order (= the order of the KFD topology's GPU nodes) with the
+    PCI address, NUMA node and local CPUs of each, read from sysfs WITHOUT touching the GPU (a rank calls this before its
+    first HIP call): [{"index", "pci", "numa_node", "cpus"}].  Empty when the machine has no KFD topology (a CPU box)."""
+    nodes_dir = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    out = []
+    try:
+        names = sorted(os.listdir(nodes_dir), key=lambda n: int(n))
+    except (OSError, ValueError):
+        return out
+    for n in names:
+        props = {}
+        try:
+            with open(os.path.join(nodes_dir, n, "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    if v.strip().lstrip("-").isdigit():
+                        props[k] = int(v)
+        except OSError:
+            continue
+        if props.get("simd_count", 0) <= 0:          # a CPU node
+            continue
+        loc, dom = props.get("location_id", 0), props.get("domain", 0)
+        pci = "%04x:%02x:%02x.%x" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 0x7)
+        numa, cpus = -1, []
+        try:
+            with open(os.path.join(sysfs, "bus", "pci", "devices", pci, "numa_node")) as f:
+                numa = int(f.read().strip())
+            with open(os.path.join(sysfs, "bus", "pci", "devices", pci, "local_cpulist")) as f:
+                cpus = _parse_cpulist(f.read())
+        except (OSError, ValueError):
+            pass
+        out.append({"index": len(out), "pci": pci, "numa_node": numa, "cpus": cpus})
+    return out
+
+
+def cpus_for_local_rank(topology: List[Dict], local_rank: int, n_local: int, allowed: Optional[Sequence[int]] = None) -> List[int]:
+    """The host CPUs rank `local_rank` of `n_local` on this node should run on: the CPUs local to ITS GPU's NUMA node, cut
+    into equal contiguous shares among the local ranks whose GPUs sit on the same node (8 GPUs on 2 sockets: 4 ranks per
+    socket, a quarter of the socket's CPUs each), intersected with what the process may use at all (`allowed`: a cgroup /
+    taskset).  [] = no recommendation (no topology, GPU without a NUMA node, or nothing left after the intersection)."""
+    if not topology or not (0 <= local_rank < len(topology)):
+        return []
+    me = topology[local_rank]
+    cpus = sorted(me["cpus"])
+    if allowed is not None:
+        ok = set(allowed)
+        cpus = [c for c in cpus if c in ok]
+    if not cpus:
+        return []
+    same = [g["index"] for g in topology[:max(n_local, local_rank + 1)] if g["numa_node"] == me["numa_node"] and g["cpus"] == me["cpus"]]
+    k, n = same.index(local_rank), len(same)
+    per = len(cpus) // n
+    if per == 0:
+        return cpus
+    return cpus[k * per:(k + 1) * per]
+
+
+def bind_rank(local_rank: int, n_local: int, sysfs: str = "/sys", num_threads: int = 4) -> Dict:
+    """Called by every rank of a multi-GPU job BEFORE its first GPU call: pins the process (the calling thread; the threads
+    HIP / RCCL start later inherit it) to the CPUs of its GPU's NUMA node (cpus_for_local_rank) and caps torch's intra-op
+    CPU threads (the render loop is one Python thread issuing ~25 launches per 0.36 ms frame: eight such hosts left to the
+    scheduler land on one socket as easily as not).  SC_BIND_CPUS=0 switches it off.  All GPUs stay VISIBLE to every rank
+    (torch.cuda.set_device(local_rank) selects one): RCCL's xGMI transport maps its peers' buffers through hipIpc /
+    peer access, which needs the peer devices enumerated in the process; per-rank HIP_VISIBLE_DEVICES is the configuration
+    RCCL falls back to host shared memory on.  Returns what was done (for the bench line)."""
+    info = {"local_rank": int(local_rank), "bound": False, "cpus": None, "numa_node": None, "pci": None}
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return info
+    info["cpus_before"] = len(allowed)
+    if os.environ.get("SC_BIND_CPUS", "1") == "0":
+        info["why"] = "SC_BIND_CPUS=0"
+        return info
+    topo = gpu_host_topology(sysfs)
+    if topo and 0 <= local_rank < len(topo):
+        info["numa_node"], info["pci"] = topo[local_rank]["numa_node"], topo[local_rank]["pci"]
+    cpus = cpus_for_local_rank(topo, local_rank, n_local, allowed)
+    if not cpus:
+        info["why"] = "no KFD topology / NUMA information for this GPU, or no local CPU is allowed to this process"
+        return info
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        info["why"] = f"sched_setaffinity failed: {e}"
+        return info
+    torch.set_num_threads(max(1, min(int(num_threads), len(cpus))))
+    info.update(bound=True, cpus=f"{cpus[0]}-{cpus[-1]} ({len(cpus)})" if cpus == list(range(cpus[0], cpus[-1] + 1))
+                else ",".join(map(str, cpus)), torch_threads=torch.get_num_threads())
+    return info
+
+
 # ---- single-node launcher -----------------------------------------------------------------------
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:

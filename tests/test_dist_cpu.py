@@ -215,3 +215,66 @@ def test_forced_collective_sends_a_world_of_one_through_the_real_ring():
     assert p.exitcode == 0
     assert q.get(timeout=5) == (True, 4, True, 4)
     assert q.get(timeout=5) == 0
+
+
+def _fake_sysfs(root, gpus, cpu_nodes=2):
+    """A sysfs tree with `cpu_nodes` CPU nodes followed by GPU nodes (pci bus, numa node, cpulist) in KFD order."""
+    import os
+    nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    k = 0
+    for _ in range(cpu_nodes):
+        os.makedirs(os.path.join(nodes, str(k)))
+        open(os.path.join(nodes, str(k), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+        k += 1
+    for bus, numa, cpulist in gpus:
+        os.makedirs(os.path.join(nodes, str(k)))
+        open(os.path.join(nodes, str(k), "properties"), "w").write(
+            f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\nunique_id 123456789012\n")
+        d = os.path.join(root, "bus", "pci", "devices", "0000:%02x:00.0" % bus)
+        os.makedirs(d)
+        open(os.path.join(d, "numa_node"), "w").write(f"{numa}\n")
+        open(os.path.join(d, "local_cpulist"), "w").write(cpulist + "\n")
+        k += 1
+
+
+def test_rank_placement_maps_every_rank_to_its_gpus_numa_cpus(tmp_path):
+    """dist.gpu_host_topology / cpus_for_local_rank / bind_rank: eight GPUs on two sockets -> four ranks
+    per socket, each a contiguous quarter of the socket's CPUs (hyper-thread ranges included), intersected with what the
+    process may use; a machine without the information gets no binding, never an error."""
+    import os
+    from street_crafter_amd import dist as D
+    root = str(tmp_path)
+    _fake_sysfs(root, [(0x05 + 0x10 * i, 0 if i < 4 else 1, "0-31,64-95" if i < 4 else "32-63,96-127") for i in range(8)])
+    topo = D.gpu_host_topology(root)
+    assert [g["index"] for g in topo] == list(range(8)) and topo[0]["pci"] == "0000:05:00.0" and topo[7]["numa_node"] == 1
+    assert topo[5]["cpus"][:2] == [32, 33] and len(topo[5]["cpus"]) == 64
+    shares = [D.cpus_for_local_rank(topo, r, 8) for r in range(8)]
+    assert all(len(s) == 16 for s in shares)
+    assert sorted(sum(shares[:4], [])) == topo[0]["cpus"] and sorted(sum(shares[4:], [])) == topo[4]["cpus"]
+    assert len(set(map(tuple, shares))) == 8                                # disjoint
+    assert D.cpus_for_local_rank(topo, 1, 2) == topo[0]["cpus"][32:]        # two local ranks: halves of socket 0
+    assert D.cpus_for_local_rank(topo, 6, 8, allowed=range(40, 48)) == [44, 45]      # cgroup: 8 CPUs of socket 1, a quarter
+    assert D.cpus_for_local_rank(topo, 2, 8, allowed=range(40, 48)) == []            # nothing local is allowed: no binding
+    assert D.cpus_for_local_rank(topo, 9, 8) == [] and D.cpus_for_local_rank([], 0, 8) == []
+    assert D.gpu_host_topology(os.path.join(root, "nope")) == []
+    # a GPU without NUMA information (numa_node -1, whole machine as its cpulist): shares among all eight
+    root2 = str(tmp_path / "flat")
+    _fake_sysfs(root2, [(0x10 + i, -1, "0-15") for i in range(4)])
+    t2 = D.gpu_host_topology(root2)
+    assert [D.cpus_for_local_rank(t2, r, 4) for r in range(4)] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    # bind_rank in a child process (it changes the affinity of the caller): with this container's CPUs standing in
+    import subprocess, sys, json
+    allowed = sorted(os.sched_getaffinity(0))
+    root3 = str(tmp_path / "here")
+    _fake_sysfs(root3, [(0x20 + i, 0, ",".join(map(str, allowed))) for i in range(2)])
+    code = ("import json, os, sys; sys.path.insert(0, %r); from street_crafter_amd import dist as D; "
+            "i = D.bind_rank(1, 2, sysfs=%r); print(json.dumps([i, sorted(os.sched_getaffinity(0))]))" % (os.getcwd(), root3))
+    info, now = json.loads(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip().splitlines()[-1])
+    if len(allowed) >= 2:
+        assert info["bound"] and now == allowed[len(allowed) // 2:][:len(allowed) // 2] and info["numa_node"] == 0
+    off = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, SC_BIND_CPUS="0"),
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip().splitlines()[-1]
+    assert json.loads(off)[0]["bound"] is False and json.loads(off)[1] == allowed
+
