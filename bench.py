@@ -542,9 +542,9 @@ def run_rank(args):
         t1 = time.perf_counter()
         return t1 - t0, t1 - t_submitted, frames
 
-    spec0 = dict(rendering._BIN_STATS) if not selftest else None
+    spec0 = dict(rendering._STATE.stats) if not selftest else None
     elapsed_local, drain_s, frames = timed_run(render_into, gatherer, rec=main_rec)
-    spec = None if selftest else {k: rendering._BIN_STATS[k] - spec0[k] for k in spec0}
+    spec = None if selftest else {k: rendering._STATE.stats[k] - spec0[k] for k in spec0}
     elapsed = elapsed_local
     per_rank_fps = [args.steps / elapsed_local]
     if world > 1:
@@ -696,7 +696,7 @@ def run_rank(args):
                 fg, sky = fg.to(dev), sky.to(dev)
                 ev_st = {}
                 key = (dev.index, 1, n_st, 16, math.ceil(W / 16), math.ceil(H / 16))
-                rendering._BIN_LAST_META.pop(key, None)          # (keyed by shape: S-1M's entry has the same key)
+                rendering._STATE.last_meta.pop(key, None)          # (keyed by shape: S-1M's entry has the same key)
 
                 def street_into(s, out, events=None, intermediates=False, fg=fg, ev_st=ev_st):
                     with torch.no_grad():
@@ -712,7 +712,7 @@ def run_rank(args):
                 # after a host round trip, which a mean would carry)
                 d["stage_ms"] = {k: sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2] for k, v in ev_st.items()}
                 d["stage_ms_is"] = "median over the probe frames"
-                meta = rendering._BIN_LAST_META.get(key)
+                meta = rendering._STATE.last_meta.get(key)
                 if meta:
                     d["largest_super_tile_records"] = meta[2]
                     d["isect_route"] = "bucketed"
@@ -958,7 +958,7 @@ def run_rank(args):
                        "n_gaussians": args.n_gauss, "n_isects_mean": I_mean, "rho": I_mean / args.n_gauss,
                        "isect_mode": rendering._ISECT_MODE["mode"], "frames_in_flight": n_streams,
                        "render_colors_storage": "planar (one plane per channel behind the [C,H,W,D] indexing)"
-                                                if rendering._PLANAR_OUT["on"] else "interleaved",
+                                                if rendering._SWITCH.planar_out else "interleaved",
                        "raster_side_stream_cus": args.raster_cus,
                        "isect_speculation": dict(spec, what="isect_tiles calls of the headline run incl. warm-up: "
                                                  "speculative_ok = the scatter + sort launched with sizes predicted "
@@ -966,7 +966,7 @@ def run_rank(args):
                                                  "exact_relaunch = the prediction was too small and they were "
                                                  "launched again with exact sizes; the rest had no prediction yet"),
                        "isect_ids": "lazy (written on first read; nothing on this path reads them)"
-                                    if rendering._LAZY_ISECT_IDS["on"] else "written by the sort",
+                                    if rendering._SWITCH.lazy_ids else "written by the sort",
                        "parallelism": f"frames x{world}"},
             "roofline": roofline,
             "operators": operators,

@@ -136,6 +136,15 @@ class LazyTensor(torch.Tensor):
         memo[id(self)] = out
         return out
 
+    # DLPack: torch.from_dlpack(t) / cupy.from_dlpack(t) / ... ask the OBJECT for its capsule, so the contents can be settled
+    # first.  (The legacy torch.utils.dlpack.to_dlpack(t) unwraps the tensor in C++ without any hook: it would export the
+    # placeholder -- call t.materialize() first, or switch the deferral off: SC_DEFER_ISECT=0 SC_LAZY_IDS=0, INTEGRATION.md.)
+    def __dlpack__(self, *args, **kwargs):
+        self.materialize()
+        self.__dict__["_sc_touched"] = True
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).__dlpack__(*args, **kwargs)
+
     def __reduce_ex__(self, proto):
         return self.materialize().as_subclass(torch.Tensor).__reduce_ex__(proto)
 

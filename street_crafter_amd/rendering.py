@@ -15,6 +15,8 @@ import threading
 import weakref
 from typing import Optional, Tuple
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -23,6 +25,78 @@ from .lazy import LazyTensor as _LazyTensor
 
 __all__ = ["fully_fused_projection", "isect_tiles", "isect_offset_encode", "spherical_harmonics",
            "rasterize_to_pixels", "rasterization"]
+
+def _env_on(name: str, default: bool = True) -> bool:
+    v = os.environ.get(name)
+    return default if v is None or v == "" else v not in ("0", "false", "False", "off", "no")
+
+
+class _Switches:
+    """The A/B switches of the operators: ONE object, every attribute settable through its set_* function below and
+    initialised from the environment, so that a user who cannot touch code can still turn a behaviour off.  None of them
+    changes a result.
+        SC_DEFER_ISECT=0   isect_tiles waits for the frame's intersection count inside the call (set_deferred_isect)
+        SC_LAZY_IDS=0      isect_tiles' isect_ids are written by the sort instead of on first read (set_lazy_isect_ids)
+      -> with BOTH off, flatten_ids / isect_ids are ordinary, fully written tensors the moment isect_tiles returns: what a
+         caller needs who hands them to foreign C++ / DLPack consumers without a torch call in between
+        SC_PLANAR_OUTPUT=0 render_colors interleaved under no_grad too (set_planar_output)
+        SC_TILE_ORDER=0    no dispatch list for the rasterizer (set_tile_order)
+        SC_VIEW_SLOTS=0    one work hint for all views (set_view_slots)
+        SC_PACKED_RECORDS=0  the fused forward writes the four per-splat arrays instead of packed records (set_packed_records)"""
+    __slots__ = ("tile_order", "lazy_ids", "view_slots", "packed_records", "defer_isect", "planar_out")
+
+    def __init__(self):
+        self.tile_order = _env_on("SC_TILE_ORDER")
+        self.lazy_ids = _env_on("SC_LAZY_IDS")
+        self.view_slots = _env_on("SC_VIEW_SLOTS")
+        self.packed_records = _env_on("SC_PACKED_RECORDS")
+        self.defer_isect = _env_on("SC_DEFER_ISECT")
+        self.planar_out = _env_on("SC_PLANAR_OUTPUT")
+
+    def flip(self, name: str, value: bool) -> bool:
+        prev = getattr(self, name)
+        setattr(self, name, bool(value))
+        return prev
+
+
+class _OperatorState:
+    """Everything the operators remember BETWEEN calls, in one place (round 3 had eleven module-level tables).  Every
+    entry is a hint the kernels verify on the device or that only orders work: dropping any of it (reset_state) never
+    changes a result.  All tables are keyed by the device index first; `reset(device)` forgets one device's entries.
+      prediction  (device, C, N, tile_size, tile_width, tile_height) -> (capacity, rec_capacity, super_capacity) the next
+                  isect_tiles of this frame shape launches its scatter + sort with, before the host has read the counts
+      history     same key -> the sizes of the last `history_len` calls (the prediction covers the largest of them)
+      last_meta   same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
+      tile_work   (device, C, N, tile_width, tile_height) -> int32 [view slots, C * tiles]: what every tile walked the last
+                  time a frame of this shape was rasterized (the rasterizer's scheduling hint)
+      view_registry  device -> int32 [sc_view_registry_words()]: the device-side table forward axis -> view slot
+      stats       how often the predicted sizes held (bench.py reports it)"""
+    KEYS_MAX = 64        # frame shapes remembered in prediction / history / last_meta (pruned together)
+
+    def __init__(self):
+        self.prediction, self.history, self.last_meta = {}, {}, {}
+        self.history_len = 8     # (tools/exp_camera_rig.py sets 1 for its A/B: round 2's first form)
+        self.tile_work, self.view_registry = {}, {}
+        self.stats = {"calls": 0, "speculative_ok": 0, "exact_relaunch": 0}
+        self.bucket_cap = {}     # "v": sc_isect_bin_bucket_capacity()
+        self.sched_sizes = {}    # tiles -> (words of the work-hint buffer, items of the dispatch list)
+
+    def tables(self):
+        return (("predictions", self.prediction), ("history", self.history), ("last_meta", self.last_meta),
+                ("tile_work", self.tile_work), ("view_registry", self.view_registry))
+
+    def reset(self, idx=None) -> dict:
+        dropped = {}
+        for name, table in self.tables():
+            keys = [k for k in table if idx is None or (k[0] if isinstance(k, tuple) else k) == idx]
+            for k in keys:
+                table.pop(k, None)
+            dropped[name] = len(keys)
+        return dropped
+
+
+_SWITCH = _Switches()
+_STATE = _OperatorState()
 
 # "bin"  : tile-bucketed count + in-LDS per-tile sort (default once available)
 # "radix": reference-shaped count -> emit -> device-wide radix sort
@@ -362,48 +436,37 @@ def _check_isect_count(n_isects, C, N, tile_width, tile_height):
 # enqueued with predicted buffer sizes BEFORE the host has read the counts back, so the GPU never
 # idles on the host round-trip.  The kernels verify the prediction on the device (see
 # sc_isect_bin_sort) and the wrapper retries with exact sizes when it was too small.
-_BIN_PREDICTION = {}
-_BIN_HISTORY = {}      # same key -> the sizes of the last 8 calls (the prediction covers the largest of them)
-_BIN_HISTORY_LEN = 8   # (tools/exp_camera_rig.py sets 1 for its A/B: round 2's first form)
-_BIN_KEYS_MAX = 64     # shapes remembered in _BIN_HISTORY / _BIN_PREDICTION / _BIN_LAST_META (pruned together)
-_TILE_WORK = {}        # (device index, C, N, tile_width, tile_height) -> int32 [view slots, C * tiles]: the list entries every tile
-                       # walked the last time a frame of this shape was rasterized (the rasterizer's scheduling hint)
-_TILE_ORDER = {"on": True}
-_LAZY_ISECT_IDS = {"on": True}
-_VIEW_SLOTS = {"on": True}
-_PACKED_RECORDS = {"on": True}
-_VIEW_REGISTRY = {}    # device index -> int32 [sc_view_registry_words()]: the device-side table forward axis -> view slot
 
 
 def set_tile_order(enabled: bool) -> bool:
     """Longest-running-tile-first dispatch of the rasterizer (A/B switch; results are identical either way).
     Returns the previous setting."""
-    prev, _TILE_ORDER["on"] = _TILE_ORDER["on"], bool(enabled)
+    prev, _SWITCH.tile_order = _SWITCH.tile_order, bool(enabled)
     return prev
 
 
 def set_packed_records(enabled: bool) -> bool:
     """A/B switch of the fused forward's packed rasterizer records (results are identical either way).  Returns the
     previous setting."""
-    prev, _PACKED_RECORDS["on"] = _PACKED_RECORDS["on"], bool(enabled)
+    prev, _SWITCH.packed_records = _SWITCH.packed_records, bool(enabled)
     return prev
 
 
 def set_view_slots(enabled: bool) -> bool:
     """The rasterizer's work hint per VIEW (A/B switch; results are identical either way): a rig's cameras rendered
     in turn each find the hint their own last frame left.  Returns the previous setting."""
-    prev, _VIEW_SLOTS["on"] = _VIEW_SLOTS["on"], bool(enabled)
+    prev, _SWITCH.view_slots = _SWITCH.view_slots, bool(enabled)
     return prev
 
 
 def _view_registry(dev) -> Optional[Tensor]:
     """The device-side table forward axis -> view slot of `dev` (sc_isect_bin_count looks the frame's camera up in
     it, no host round trip), or None when the dispatch list / the slots are off."""
-    if not (_VIEW_SLOTS["on"] and _TILE_ORDER["on"]):
+    if not (_SWITCH.view_slots and _SWITCH.tile_order):
         return None
-    reg = _VIEW_REGISTRY.get(dev.index)
+    reg = _STATE.view_registry.get(dev.index)
     if reg is None:
-        reg = _VIEW_REGISTRY[dev.index] = torch.zeros(_lib.load().sc_view_registry_words(), dtype=torch.int32, device=dev)
+        reg = _STATE.view_registry[dev.index] = torch.zeros(_lib.load().sc_view_registry_words(), dtype=torch.int32, device=dev)
     return reg
 
 
@@ -412,14 +475,14 @@ def _tile_work(dev, C, N, tile_width, tile_height) -> Tensor:
     of a novel-view frame have the same frame shape and must not feed each other's dispatch list.  At most 8
     buffers are kept (densification changes N every few hundred training steps)."""
     key = (dev.index, int(C), int(N), int(tile_width), int(tile_height))
-    t = _TILE_WORK.pop(key, None)
+    t = _STATE.tile_work.pop(key, None)
     if t is None:
         # one bank of C * tiles words per view slot (the kernels pick the bank: sc_common.h)
         t = torch.zeros(_lib.load().sc_view_slots() * int(C) * int(tile_width) * int(tile_height), dtype=torch.int32,
                         device=dev)
-        while len(_TILE_WORK) >= 8:
-            _TILE_WORK.pop(next(iter(_TILE_WORK)))
-    _TILE_WORK[key] = t                  # (re-inserted: dicts keep insertion order, the first key is the oldest)
+        while len(_STATE.tile_work) >= 8:
+            _STATE.tile_work.pop(next(iter(_STATE.tile_work)))
+    _STATE.tile_work[key] = t                  # (re-inserted: dicts keep insertion order, the first key is the oldest)
     return t
 
 
@@ -427,17 +490,13 @@ def set_lazy_isect_ids(enabled: bool) -> bool:
     """isect_tiles' `isect_ids` on the tile-bucketed path: True (default) = a LazyTensor filled on first use
     (street_crafter_amd/lazy.py: the reference's path never reads it), False = written by the sort as before.
     Returns the previous setting."""
-    prev, _LAZY_ISECT_IDS["on"] = _LAZY_ISECT_IDS["on"], bool(enabled)
+    prev, _SWITCH.lazy_ids = _SWITCH.lazy_ids, bool(enabled)
     return prev
 
-_BIN_LAST_META = {}    # same key -> (n_isects, n_records, largest super-tile) of the last call (diagnostics, tests)
-_BIN_STATS = {"calls": 0, "speculative_ok": 0, "exact_relaunch": 0}   # how often the predicted sizes held (bench.py reports it)
 _PINNED_META = threading.local()   # .slots: device index -> [pinned int64[8] the device publishes meta into, its
                                    # numpy view, seq] of THIS host thread
 
 
-_DEFER_ISECT = {"on": True}
-_BUCKET_CAP = {}       # "v": sc_isect_bin_bucket_capacity()
 
 
 def set_deferred_isect(enabled: bool) -> bool:
@@ -445,7 +504,7 @@ def set_deferred_isect(enabled: bool) -> bool:
     `flatten_ids` / `isect_ids` (normally inside rasterize_to_pixels, by when the count has long arrived: lazy.py), False =
     inside isect_tiles as before.  Applies when a prediction of the buffer sizes exists (from the second call of a frame
     shape on).  Results are identical either way.  Returns the previous setting."""
-    prev, _DEFER_ISECT["on"] = _DEFER_ISECT["on"], bool(enabled)
+    prev, _SWITCH.defer_isect = _SWITCH.defer_isect, bool(enabled)
     return prev
 
 
@@ -530,7 +589,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
     seq = slot[2]
     # the rasterizer's dispatch order (longest-running tiles first) is built here, beside the count kernels, from
     # what every tile walked the last time (tile_size 16: the wave-per-tile rasterizer)
-    want_order = _TILE_ORDER["on"] and int(tile_size) == 16
+    want_order = _SWITCH.tile_order and int(tile_size) == 16
     work = _tile_work(dev, C, N, tile_width, tile_height) if want_order else None
     registry = None
     if (want_order and viewmats is not None and viewmats.device == dev and viewmats.dtype == torch.float32
@@ -577,7 +636,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             return tuple(int(v) for v in meta_dev.cpu().tolist())
         return int(meta_np[0]), int(meta_np[1]), int(meta_np[2]), int(meta_np[3])
 
-    eager_ids = want_ids and not _LAZY_ISECT_IDS["on"]
+    eager_ids = want_ids and not _SWITCH.lazy_ids
 
     def launch(capacity, rec_capacity, super_capacity):
         if fast is not None:
@@ -593,7 +652,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         return r, ids, fids
 
     key = (dev.index, C, N, int(tile_size), int(tile_width), int(tile_height))
-    pred = _BIN_PREDICTION.get(key)
+    pred = _STATE.prediction.get(key)
     rc, ids, fids = (None, None, None)
     if pred is not None:
         rc, ids, fids = launch(*pred)
@@ -609,11 +668,11 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         _check_isect_count(n_isects, C, N, tile_width, tile_height)
         # the device ran the predicted launch iff ALL THREE of its checks passed; `_bin_launch_ran` restates those
         # checks exactly (a launch that ran in full has consumed the bucket cursors: it must never be repeated)
-        _BIN_STATS["calls"] += 1
+        _STATE.stats["calls"] += 1
         if rc is not None and _bin_launch_ran(pred, n_isects, n_records, max_super):
-            _BIN_STATS["speculative_ok"] += 1
+            _STATE.stats["speculative_ok"] += 1
         elif rc is not None:
-            _BIN_STATS["exact_relaunch"] += 1
+            _STATE.stats["exact_relaunch"] += 1
         if rc is None or not _bin_launch_ran(pred, n_isects, n_records, max_super):
             if rc is not None:     # a predicted launch was enqueued and (by the device's own check) did nothing:
                 # belt and braces, the cursors are re-zeroed before the exact-size launch all the same
@@ -627,20 +686,20 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
             if rc == -3:
                 return None
             _lib.check(rc, "sc_isect_bin_sort")
-        _BIN_LAST_META[key] = (n_isects, n_records, max_super)
+        _STATE.last_meta[key] = (n_isects, n_records, max_super)
         # next call: 12.5 % head-room over the largest of the last 8 calls of this shape (a rig's cameras are rendered
         # in turn and see different amounts of the scene: sized by the previous call alone, every switch to a fuller view
         # missed the prediction and paid the host round trip + a second launch)
-        hist = _BIN_HISTORY.get(key)
+        hist = _STATE.history.get(key)
         if hist is None:
-            hist = _BIN_HISTORY[key] = collections.deque(maxlen=_BIN_HISTORY_LEN)
-            while len(_BIN_HISTORY) > _BIN_KEYS_MAX:
+            hist = _STATE.history[key] = collections.deque(maxlen=_STATE.history_len)
+            while len(_STATE.history) > _STATE.KEYS_MAX:
                 # one key per distinct (device, C, N, tile grid): densification changes N every 100 training iterations
                 # (train.py:292-310), so all three per-shape tables are pruned together, oldest shape first
-                old = next(iter(_BIN_HISTORY))
-                _BIN_HISTORY.pop(old)
-                _BIN_PREDICTION.pop(old, None)
-                _BIN_LAST_META.pop(old, None)
+                old = next(iter(_STATE.history))
+                _STATE.history.pop(old)
+                _STATE.prediction.pop(old, None)
+                _STATE.last_meta.pop(old, None)
         hist.append((n_isects, n_records, max_super))
         mi, mr, ms = map(max, zip(*hist))
         ms_pred = ms + ms // 8 + 64
@@ -648,12 +707,12 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
         #  frame also launches the split kernel and ~10 k idle segment workgroups -- 8-10 us at the training resolution,
         #  whose largest bucket sits just below it.  A frame that does exceed it fails the device-side check and is
         #  relaunched with exact sizes, and the history then provisions for it.)
-        cap1 = _BUCKET_CAP.get("v")
+        cap1 = _STATE.bucket_cap.get("v")
         if cap1 is None:
-            cap1 = _BUCKET_CAP["v"] = int(lib.sc_isect_bin_bucket_capacity())
+            cap1 = _STATE.bucket_cap["v"] = int(lib.sc_isect_bin_bucket_capacity())
         if ms <= cap1 < ms_pred:
             ms_pred = cap1
-        _BIN_PREDICTION[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms_pred)
+        _STATE.prediction[key] = (mi + mi // 8 + 4096, mr + mr // 8 + 4096, ms_pred)
         return n_isects, ids, fids
 
     def make_fill(get_flat, n_isects_of):
@@ -670,7 +729,7 @@ def _isect_tiles_bin(lib, means2d, radii, depths, C, N, tile_size, tile_width, t
                                                 cur), "sc_isect_ids_rebuild")
         return fill
 
-    if defer and rc == 0 and want_ids and not eager_ids and _DEFER_ISECT["on"]:
+    if defer and rc == 0 and want_ids and not eager_ids and _SWITCH.defer_isect:
         # The predicted scatter + sort are enqueued; the wait for the counts, the check of the prediction and the true
         # length of the two id tensors are settled on their first observation (lazy.py) -- on the reference's path
         # inside rasterize_to_pixels, three torch calls later, when the counts have arrived.
@@ -824,8 +883,6 @@ def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor,
 # ------------------------------------------------------------------------------------------
 # a9 rasterize_to_pixels  (renderer.py:267-280)
 # ------------------------------------------------------------------------------------------
-_SCHED_SIZES = {}      # tiles -> (words of the work-hint buffer, items of the dispatch list)
-_PLANAR_OUT = {"on": True}
 
 
 def set_planar_output(enabled: bool) -> bool:
@@ -836,7 +893,7 @@ def set_planar_output(enabled: bool) -> bool:
     strided ones (-10 us per 1920x1280 frame, tools/exp_glue_layout.py).  The tensor is not `is_contiguous()` in this form
     (`.view(-1)` on it needs `.reshape`).  Training (anything requires grad) always takes the interleaved form.  Returns the
     previous setting."""
-    prev, _PLANAR_OUT["on"] = _PLANAR_OUT["on"], bool(enabled)
+    prev, _SWITCH.planar_out = _SWITCH.planar_out, bool(enabled)
     return prev
 
 
@@ -886,26 +943,19 @@ def reset_state(device=None) -> dict:
                 except Exception as e:      # noqa: BLE001  (stays on the pending call's own tensors)
                     _warn_once("settle_reset", "reset_state: settling a never observed isect_tiles call failed (%s: %s)",
                                type(e).__name__, e)
-    dropped = {}
-    for name, table in (("predictions", _BIN_PREDICTION), ("history", _BIN_HISTORY), ("last_meta", _BIN_LAST_META),
-                        ("tile_work", _TILE_WORK), ("view_registry", _VIEW_REGISTRY)):
-        keys = [k for k in table if idx is None or (k[0] if isinstance(k, tuple) else k) == idx]
-        for k in keys:
-            table.pop(k, None)
-        dropped[name] = len(keys)
-    return dropped
+    return _STATE.reset(idx)
 
 
 def _sched_of(isect_offsets, n_tiles):
     """(tile_order, tile_work) the intersection stage left on this isect_offsets tensor, or (None, None)."""
-    sched = getattr(isect_offsets, "_sc_sched", None) if _TILE_ORDER["on"] else None
+    sched = getattr(isect_offsets, "_sc_sched", None) if _SWITCH.tile_order else None
     if sched is None:
         return None, None
-    want = _SCHED_SIZES.get(n_tiles)
+    want = _STATE.sched_sizes.get(n_tiles)
     if want is None:       # (two foreign calls per frame otherwise)
-        if len(_SCHED_SIZES) > 64:
-            _SCHED_SIZES.clear()
-        want = _SCHED_SIZES[n_tiles] = (_lib.load().sc_view_slots() * n_tiles, _lib.load().sc_tile_order_len(n_tiles))
+        if len(_STATE.sched_sizes) > 64:
+            _STATE.sched_sizes.clear()
+        want = _STATE.sched_sizes[n_tiles] = (_lib.load().sc_view_slots() * n_tiles, _lib.load().sc_tile_order_len(n_tiles))
     if sched[1].numel() != want[0] or sched[0].device != isect_offsets.device or sched[0].numel() != want[1]:
         return None, None
     return sched
@@ -939,7 +989,7 @@ class _Rasterize(torch.autograd.Function):
                 st = side.cuda_stream
         rc = -3
         last_ids = None
-        if _PLANAR_OUT["on"] and not needs_bwd and int(tile_size) == 16 and D in (3, 4):
+        if _SWITCH.planar_out and not needs_bwd and int(tile_size) == 16 and D in (3, 4):
             # inference: one plane per channel behind the same [C,H,W,D] indexing (set_planar_output); -3 = not this kernel
             if fast is not None:
                 rc, render_colors, render_alphas = fast.rasterize_fwd_planar(
@@ -1200,7 +1250,7 @@ def _rasterization_fused(means, quats, scales, opacities, colors, viewmats, Ks, 
     # the rasterizer's 48-B record per (camera, Gaussian): one gather line per splat instead of four.  With it the
     # conics / opacities / colours arrays of `meta` are not written at all (32 B per Gaussian the frame never reads):
     # _FusedMeta rebuilds them from the records on first access
-    use_records = _PACKED_RECORDS["on"] and int(tile_size) == 16 and N > 0 and C > 0
+    use_records = _SWITCH.packed_records and int(tile_size) == 16 and N > 0 and C > 0
     records = conics = opac = cols = None
     if fast is not None:
         rc, radii, means2d, depths, records, conics, opac, cols = fast.projection_sh_fwd(

@@ -122,7 +122,7 @@ def test_work_hint_buffers_are_keyed_and_bounded():
     """The rasterizer's per-tile work hints: one buffer per (device, cameras, Gaussian count, tile grid) -- the two
     passes of a novel-view frame must not share one -- and at most 8 of them (densification changes N)."""
     from street_crafter_amd import _lib, rendering
-    rendering._TILE_WORK.clear()
+    rendering._STATE.tile_work.clear()
     dev = torch.device("cpu")
     a = rendering._tile_work(dev, 1, 1000, 4, 3)
     b = rendering._tile_work(dev, 1, 31, 4, 3)
@@ -131,31 +131,31 @@ def test_work_hint_buffers_are_keyed_and_bounded():
     assert rendering._tile_work(dev, 2, 1000, 4, 3).shape == (24 * _lib.load().sc_view_slots(),)
     for n in range(2000, 2010):
         rendering._tile_work(dev, 1, n, 4, 3)
-    assert len(rendering._TILE_WORK) == 8
-    assert rendering._tile_work(dev, 1, 2009, 4, 3) is rendering._TILE_WORK[(None, 1, 2009, 4, 3)]
-    assert (None, 1, 1000, 4, 3) not in rendering._TILE_WORK          # the oldest were dropped
-    rendering._TILE_WORK.clear()
+    assert len(rendering._STATE.tile_work) == 8
+    assert rendering._tile_work(dev, 1, 2009, 4, 3) is rendering._STATE.tile_work[(None, 1, 2009, 4, 3)]
+    assert (None, 1, 1000, 4, 3) not in rendering._STATE.tile_work          # the oldest were dropped
+    rendering._STATE.tile_work.clear()
 
 
 def test_reset_state_forgets_the_hints_between_calls_per_device():
     """rendering.reset_state: the tables the operators keep between calls (size predictions + history + last counts,
     work-hint buffers, view registries) are dropped for one device or for all; switches keep their values."""
     from street_crafter_amd import rendering
-    tables = (rendering._BIN_PREDICTION, rendering._BIN_HISTORY, rendering._BIN_LAST_META, rendering._TILE_WORK,
-              rendering._VIEW_REGISTRY)
+    tables = (rendering._STATE.prediction, rendering._STATE.history, rendering._STATE.last_meta, rendering._STATE.tile_work,
+              rendering._STATE.view_registry)
     saved = [dict(t) for t in tables]
     try:
         for t in tables:
             t.clear()
         for dev in (0, 1):
-            rendering._BIN_PREDICTION[(dev, 1, 10, 16, 4, 3)] = (1, 1, 1)
-            rendering._BIN_HISTORY[(dev, 1, 10, 16, 4, 3)] = [(1, 1, 1)]
-            rendering._BIN_LAST_META[(dev, 1, 10, 16, 4, 3)] = (1, 1, 1)
-            rendering._TILE_WORK[(dev, 1, 10, 4, 3)] = torch.zeros(4, dtype=torch.int32)
-            rendering._VIEW_REGISTRY[dev] = torch.zeros(4, dtype=torch.int32)
+            rendering._STATE.prediction[(dev, 1, 10, 16, 4, 3)] = (1, 1, 1)
+            rendering._STATE.history[(dev, 1, 10, 16, 4, 3)] = [(1, 1, 1)]
+            rendering._STATE.last_meta[(dev, 1, 10, 16, 4, 3)] = (1, 1, 1)
+            rendering._STATE.tile_work[(dev, 1, 10, 4, 3)] = torch.zeros(4, dtype=torch.int32)
+            rendering._STATE.view_registry[dev] = torch.zeros(4, dtype=torch.int32)
         prev = rendering.set_deferred_isect(False)
         assert rendering.reset_state(1) == {"predictions": 1, "history": 1, "last_meta": 1, "tile_work": 1, "view_registry": 1}
-        assert all(len(t) == 1 for t in tables) and (0, 1, 10, 16, 4, 3) in rendering._BIN_PREDICTION and 0 in rendering._VIEW_REGISTRY
+        assert all(len(t) == 1 for t in tables) and (0, 1, 10, 16, 4, 3) in rendering._STATE.prediction and 0 in rendering._STATE.view_registry
         assert rendering.reset_state(torch.device("cuda", 0))["predictions"] == 1 and not any(len(t) for t in tables)
         assert rendering.reset_state() == {"predictions": 0, "history": 0, "last_meta": 0, "tile_work": 0, "view_registry": 0}
         assert rendering.set_deferred_isect(prev) is False          # (a switch, not state: untouched)
@@ -523,3 +523,33 @@ def test_setup_py_names_the_three_packages():
     pk = set(find_packages(where=ROOT, include=["street_crafter_amd", "street_crafter_amd.*", "gsplat", "gsplat.*",
                                                 "simple_knn", "simple_knn.*"]))
     assert {"gsplat", "simple_knn", "street_crafter_amd"} <= pk
+
+
+def test_switches_come_from_the_environment_and_state_is_one_object():
+    """the operators' A/B switches live in ONE object initialised from documented environment variables
+    (a user who feeds flatten_ids to foreign C++ turns the placeholders off without touching code), and everything the
+    operators remember between calls lives in ONE state object that reset_state() empties."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from street_crafter_amd import rendering as R; s = R._SWITCH; "
+            "print(s.defer_isect, s.lazy_ids, s.planar_out, s.tile_order, s.view_slots, s.packed_records)" % ROOT)
+    env = dict(os.environ)
+    for k in ("SC_DEFER_ISECT", "SC_LAZY_IDS", "SC_PLANAR_OUTPUT", "SC_TILE_ORDER", "SC_VIEW_SLOTS", "SC_PACKED_RECORDS"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()
+    assert out == ["True"] * 6
+    env.update(SC_DEFER_ISECT="0", SC_LAZY_IDS="0", SC_PLANAR_OUTPUT="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True, env=env).stdout.split()
+    assert out == ["False", "False", "False", "True", "True", "True"]
+    from street_crafter_amd import rendering
+    assert rendering.set_deferred_isect(False) is True and rendering._SWITCH.defer_isect is False
+    assert rendering.set_deferred_isect(True) is False
+    st = rendering._STATE
+    st.prediction[(5, 1, 10, 16, 4, 3)] = (1, 1, 1)
+    st.last_meta[(6, 1, 10, 16, 4, 3)] = (1, 1, 1)
+    assert rendering.reset_state(5)["predictions"] == 1 and (6, 1, 10, 16, 4, 3) in st.last_meta
+    assert rendering.reset_state()["last_meta"] == 1 and not st.prediction and not st.last_meta
+    # no module-level table is left behind the object
+    for name in ("_BIN_PREDICTION", "_BIN_HISTORY", "_BIN_LAST_META", "_TILE_WORK", "_VIEW_REGISTRY", "_DEFER_ISECT"):
+        assert not hasattr(rendering, name)
+

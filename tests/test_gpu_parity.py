@@ -174,22 +174,22 @@ def test_isect_tiles_defers_its_host_wait_to_the_first_observation(ops):
         finally:
             rendering.set_deferred_isect(prev)
 
-    for d_ in (rendering._BIN_PREDICTION, rendering._BIN_HISTORY, rendering._BIN_LAST_META):
+    for d_ in (rendering._STATE.prediction, rendering._STATE.history, rendering._STATE.last_meta):
         d_.pop(key, None)
     a0, a1 = project(0.0), project(0.3)
     e0, e1 = eager(a0), eager(a1)                                        # (also teaches the prediction)
     assert e0[2].numel() != e1[2].numel()
     # 1. deferred, good prediction: nothing is settled by the call, by metadata that does not need the length, or by
     #    isect_offset_encode; shape / contents settle it
-    stats = dict(rendering._BIN_STATS)
+    stats = dict(rendering._STATE.stats)
     tpg, ids, fids = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
     assert type(fids) is LazyTensor and type(ids) is LazyTensor and not fids.is_resolved and not ids.is_resolved
     assert fids.dtype == torch.int32 and ids.dtype == torch.int64 and fids.is_cuda and fids.ndim == 1
     off = ops.isect_offset_encode(ids, 1, tw, th)
-    assert not fids.is_resolved and not ids.is_resolved and rendering._BIN_STATS["calls"] == stats["calls"]
+    assert not fids.is_resolved and not ids.is_resolved and rendering._STATE.stats["calls"] == stats["calls"]
     assert torch.equal(off, e0[3]) and torch.equal(tpg, e0[0])
     assert fids.shape == e0[2].shape and fids.is_resolved and ids.is_resolved and not ids.is_materialized
-    assert rendering._BIN_STATS["calls"] == stats["calls"] + 1 and rendering._BIN_STATS["speculative_ok"] == stats["speculative_ok"] + 1
+    assert rendering._STATE.stats["calls"] == stats["calls"] + 1 and rendering._STATE.stats["speculative_ok"] == stats["speculative_ok"] + 1
     assert ids.shape == e0[1].shape and torch.equal(fids, e0[2]) and torch.equal(ids, e0[1]) and ids.is_materialized
     assert torch.equal(ops.isect_offset_encode(ids, 1, tw, th), e0[3])
     # 2. the rasterizer settles it: image equal to the eager call's
@@ -205,12 +205,12 @@ def test_isect_tiles_defers_its_host_wait_to_the_first_observation(ops):
     assert torch.equal(img[0], ref[0]) and torch.equal(img[1], ref[1])
     # 3. a prediction that is too small: the settle relaunches with exact sizes; one that is generous: no relaunch
     for pred, relaunch in (((16, 16, 16), 1), ((1 << 26, 1 << 26, 3000), 0)):
-        rendering._BIN_PREDICTION[key] = pred
-        stats = dict(rendering._BIN_STATS)
+        rendering._STATE.prediction[key] = pred
+        stats = dict(rendering._STATE.stats)
         tpg, ids, fids = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
         assert not fids.is_resolved
         assert torch.equal(fids, e0[2]) and torch.equal(ids, e0[1]) and torch.equal(tpg, e0[0])
-        assert rendering._BIN_STATS["exact_relaunch"] == stats["exact_relaunch"] + relaunch
+        assert rendering._STATE.stats["exact_relaunch"] == stats["exact_relaunch"] + relaunch
     # 4. two calls in a row, the first never looked at: the second call settles it (the pinned slot is shared), and the
     #    first's tensors are still right afterwards; outputs dropped unobserved leave nothing behind
     t0 = ops.isect_tiles(a0[1], a0[0], a0[2], 16, tw, th, n_cameras=1)
@@ -375,8 +375,8 @@ def test_isect_bin_oversized_super_tiles_are_split_not_abandoned(ops, shape):
         d[0, 18000:18010] = 900.0
     e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 6, 6)
     key = (torch.cuda.current_device(), 1, N, 16, 6, 6)
-    rendering._BIN_LAST_META.pop(key, None)
-    rendering._BIN_PREDICTION.pop(key, None)
+    rendering._STATE.last_meta.pop(key, None)
+    rendering._STATE.prediction.pop(key, None)
     for _ in range(2):                        # second call: sizes predicted from the first
         tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 6, 6)
         off = ops.isect_offset_encode(ids, 1, 6, 6)
@@ -384,7 +384,7 @@ def test_isect_bin_oversized_super_tiles_are_split_not_abandoned(ops, shape):
         np.testing.assert_array_equal(_np(ids), e_ids)
         np.testing.assert_array_equal(_np(fids), e_f)
         np.testing.assert_array_equal(_np(off), O.isect_offset_encode(e_ids, 1, 6, 6))
-    assert rendering._BIN_LAST_META[key][2] > 20000           # the bucketed route ran, with a 20k+ bucket
+    assert rendering._STATE.last_meta[key][2] > 20000           # the bucketed route ran, with a 20k+ bucket
 
 
 @pytest.mark.parametrize("n_in_bucket", [120, 1000, 1024, 1030, 1290, 3500])
@@ -404,15 +404,15 @@ def test_isect_bin_small_and_large_bucket_sorts_agree_with_the_oracle(ops, n_in_
     d[0, : n_in_bucket // 3] = 12.5                                       # a third of the bucket ties on depth
     e_tpg, e_ids, e_f = O.isect_tiles(m2, r, d, 16, 12, 12)
     key = (torch.cuda.current_device(), 1, N, 16, 12, 12)
-    rendering._BIN_LAST_META.pop(key, None)
-    rendering._BIN_PREDICTION.pop(key, None)
-    rendering._BIN_HISTORY.pop(key, None)
+    rendering._STATE.last_meta.pop(key, None)
+    rendering._STATE.prediction.pop(key, None)
+    rendering._STATE.history.pop(key, None)
     for _ in range(2):
         tpg, ids, fids = ops.isect_tiles(_t(m2), _t(r, torch.int32), _t(d), 16, 12, 12)
         np.testing.assert_array_equal(_np(tpg), e_tpg)
         np.testing.assert_array_equal(_np(ids), e_ids)
         np.testing.assert_array_equal(_np(fids), e_f)
-    assert rendering._BIN_LAST_META[key][2] >= n_in_bucket                # the bucketed route ran, bucket as built
+    assert rendering._STATE.last_meta[key][2] >= n_in_bucket                # the bucketed route ran, bucket as built
 
 
 def test_isect_bin_street_scene_matches_the_radix_route(ops):
@@ -427,12 +427,12 @@ def test_isect_bin_street_scene_matches_the_radix_route(ops):
                                                         cam.viewmat.to(DEV)[None], cam.K.to(DEV)[None], 1920, 1280,
                                                         near_plane=0.001, far_plane=1000.0)
         key = (torch.cuda.current_device(), 1, scene.n, 16, 120, 80)
-        rendering._BIN_LAST_META.pop(key, None)
+        rendering._STATE.last_meta.pop(key, None)
         out = _isect_both_routes(ops, m2, r, d, 120, 80)
         for a, b, c in zip(out["bin"], out["radix"], out["bin_eager"]):
             assert torch.equal(a, b) and torch.equal(c, b)
-        assert key in rendering._BIN_LAST_META                 # the bucketed route took it
-    assert rendering._BIN_LAST_META[(torch.cuda.current_device(), 1, 400_000, 16, 120, 80)][2] > 3584
+        assert key in rendering._STATE.last_meta                 # the bucketed route took it
+    assert rendering._STATE.last_meta[(torch.cuda.current_device(), 1, 400_000, 16, 120, 80)][2] > 3584
 
 
 def test_isect_bin_4k_frame_stays_on_the_bucketed_route(ops):
@@ -448,11 +448,11 @@ def test_isect_bin_4k_frame_stays_on_the_bucketed_route(ops):
                                                     cam.viewmat.to(DEV)[None], cam.K.to(DEV)[None], W, H,
                                                     near_plane=0.001, far_plane=1000.0)
     key = (torch.cuda.current_device(), 1, sc.n, 16, 240, 135)
-    rendering._BIN_LAST_META.pop(key, None)
+    rendering._STATE.last_meta.pop(key, None)
     out = _isect_both_routes(ops, m2, r, d, 240, 135)
     for a, b in zip(out["bin"], out["radix"]):
         assert torch.equal(a, b)
-    assert key in rendering._BIN_LAST_META and int(out["bin"][1].numel()) > 1_000_000
+    assert key in rendering._STATE.last_meta and int(out["bin"][1].numel()) > 1_000_000
 
 
 @pytest.mark.parametrize("how", ["super_just_below", "super_rounding_window", "isects_too_small", "records_too_small",
@@ -478,9 +478,9 @@ def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
     finally:
         rendering.set_isect_mode(prev)
     key = (torch.cuda.current_device(), 1, sc.n, 16, tw, th)
-    rendering._BIN_PREDICTION.pop(key, None)
+    rendering._STATE.prediction.pop(key, None)
     ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)                   # learns the true sizes
-    n_is, n_rec, max_super = rendering._BIN_LAST_META[key]
+    n_is, n_rec, max_super = rendering._STATE.last_meta[key]
     assert n_is == int(e_ids.numel()) and max_super > 300
     big = 1 << 26
     window = (max_super + 255) // 256 * 256 - 255            # smallest value that rounds up to the same multiple
@@ -498,11 +498,11 @@ def test_isect_bin_mispredicted_capacities_retry_exactly_once(ops, how):
     if how == "super_rounding_window":
         assert pred[2] < max_super <= (pred[2] + 255) // 256 * 256 or max_super % 256 == 1
     for _ in range(2):                                                    # second pass: prediction learnt from the retry
-        rendering._BIN_PREDICTION[key] = pred
+        rendering._STATE.prediction[key] = pred
         tpg, ids, fids = ops.isect_tiles(m2, r, d, 16, tw, th, n_cameras=1)
         off = ops.isect_offset_encode(ids, 1, tw, th)
         assert torch.equal(tpg, e_tpg) and torch.equal(ids, e_ids) and torch.equal(fids, e_f) and torch.equal(off, e_off)
-        pred = rendering._BIN_PREDICTION[key]
+        pred = rendering._STATE.prediction[key]
     assert rendering._bin_launch_ran((10, 10, 10), 10, 10, 10) and not rendering._bin_launch_ran((10, 10, 10), 10, 10, 11)
 
 
@@ -1317,7 +1317,7 @@ def test_tile_dispatch_order_is_a_permutation_and_changes_no_pixel(ops, n_cams):
         rendering.set_tile_order(prev)
     assert all(getattr(p[2]["isect_offsets"], "_sc_sched", None) is None for p in plain)
     n_tiles = n_cams * (w // 16) * (h // 16)
-    rendering._TILE_WORK.clear()
+    rendering._STATE.tile_work.clear()
     from scipy.ndimage import maximum_filter
     split_counts, slots_seen = [], []
     for which in (0, 0, 1, 0):          # cold, warm, stale hint from scene 0, stale hint from scene 1
@@ -1425,7 +1425,7 @@ def test_tile_dispatch_order_at_odd_frame_shapes(ops, w, h, n):
     finally:
         rendering.set_tile_order(prev)
     n_tiles = ((w + 15) // 16) * ((h + 15) // 16)
-    rendering._TILE_WORK.clear()
+    rendering._STATE.tile_work.clear()
     for _ in range(3):
         rc, ra, meta = render()
         o = _np(meta["isect_offsets"]._sc_sched[0])
@@ -1521,8 +1521,8 @@ def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
         plain = [frame(c)[0] for c in cams]
     finally:
         rendering.set_view_slots(prev)
-    rendering._TILE_WORK.clear()
-    rendering._VIEW_REGISTRY.pop(dev.index, None)          # a fresh registry: slots are handed out in order
+    rendering._STATE.tile_work.clear()
+    rendering._STATE.view_registry.pop(dev.index, None)          # a fresh registry: slots are handed out in order
     slots, banks = {}, np.zeros((K_SLOTS, T), np.int32)
     for rnd in range(3):
         for i, cam in enumerate(cams):
@@ -1547,7 +1547,7 @@ def test_view_slots_keep_one_work_hint_per_camera_of_a_rig(ops):
         assert slot == s0 and slot not in slots.values()
     # the registry: 8 far-apart views fill the slots (tiny frames: only the slot matters here), views within the
     # window reuse theirs, and a ninth view takes over the least recently used slot and no other
-    rendering._VIEW_REGISTRY.pop(dev.index, None)
+    rendering._STATE.view_registry.pop(dev.index, None)
     small = make_scene(500, seed=3).to(DEV)
 
     def pick(yaw):
@@ -1575,19 +1575,19 @@ def test_speculative_sort_is_sized_for_the_fullest_of_the_recent_views(ops):
     sc = make_scene(n, seed=17, z_range=(1.0, 30.0)).to(DEV)
     cams = [make_camera(w, h, 500.0, 500.0, yaw=0.0).to(DEV), make_camera(w, h, 500.0, 500.0, yaw=0.75).to(DEV)]
     key = (torch.cuda.current_device(), 1, n, 16, w // 16, h // 16)
-    for d in (rendering._BIN_PREDICTION, rendering._BIN_HISTORY, rendering._BIN_LAST_META):
+    for d in (rendering._STATE.prediction, rendering._STATE.history, rendering._STATE.last_meta):
         d.pop(key, None)
     sizes, frames = [], []
     with torch.no_grad():
         for f in range(8):
             if f == 4:
-                before = dict(rendering._BIN_STATS)
+                before = dict(rendering._STATE.stats)
             o = render_gaussians(sc, cams[f % 2], return_intermediates=True)
             sizes.append(int(o["_flatten_ids"].numel()))
             frames.append(_np(o["_render_colors"]))
     assert sizes[0] > 2 * sizes[1] > 0 and sizes[:2] * 3 == sizes[2:]
-    assert rendering._BIN_STATS["exact_relaunch"] == before["exact_relaunch"]
-    assert rendering._BIN_STATS["speculative_ok"] == before["speculative_ok"] + 4
+    assert rendering._STATE.stats["exact_relaunch"] == before["exact_relaunch"]
+    assert rendering._STATE.stats["speculative_ok"] == before["speculative_ok"] + 4
     for f in range(2, 8):
         np.testing.assert_array_equal(frames[f].view(np.uint32), frames[f - 2].view(np.uint32))
 
@@ -1682,14 +1682,14 @@ def test_per_shape_tables_are_pruned_together(ops):
     sc = make_scene(400, seed=3, z_range=(1.0, 10.0)).to(DEV)
     w2c, K = cam.viewmat[None], cam.K[None]
     with torch.no_grad():
-        for n in range(300, 300 + rendering._BIN_KEYS_MAX + 12):
+        for n in range(300, 300 + rendering._STATE.KEYS_MAX + 12):
             r, m2, d, _, _ = ops.fully_fused_projection(sc.means[:n], None, sc.quats[:n], sc.scales[:n], w2c, K, 128, 96)
             ops.isect_tiles(m2, r, d, 16, 8, 6, n_cameras=1)
     torch.cuda.synchronize()
-    keys = set(rendering._BIN_HISTORY)
-    assert len(keys) == rendering._BIN_KEYS_MAX
-    assert set(rendering._BIN_PREDICTION) <= keys and set(rendering._BIN_LAST_META) <= keys
-    newest = (torch.device(DEV).index or 0, 1, 300 + rendering._BIN_KEYS_MAX + 11, 16, 8, 6)
+    keys = set(rendering._STATE.history)
+    assert len(keys) == rendering._STATE.KEYS_MAX
+    assert set(rendering._STATE.prediction) <= keys and set(rendering._STATE.last_meta) <= keys
+    newest = (torch.device(DEV).index or 0, 1, 300 + rendering._STATE.KEYS_MAX + 11, 16, 8, 6)
     assert any(k[2] == newest[2] for k in keys) and not any(k[2] == 300 and k[4:] == (8, 6) for k in keys)
 
 
@@ -1939,6 +1939,42 @@ def test_rasterizer_on_a_cu_masked_or_prioritised_side_stream_renders_the_same_f
     assert not rendering._RASTER_SIDE
 
 
+@pytest.mark.parametrize("placeholders", [True, False])
+def test_flatten_ids_handed_to_a_dlpack_consumer_right_after_isect_tiles(ops, golden_dir, placeholders):
+    """what `flatten_ids` / `isect_ids` are until first use.  Default (placeholders on): LazyTensors whose
+    length / contents are settled on first observation -- the DLPack PROTOCOL (torch.from_dlpack, i.e. `__dlpack__`) settles
+    them, and after `.materialize()` so does the legacy capsule call; with SC_DEFER_ISECT=0 SC_LAZY_IDS=0 (here: the set_*
+    switches) they are ordinary, fully written tensors the moment isect_tiles returns, and the legacy
+    torch.utils.dlpack.to_dlpack -- which unwraps the tensor in C++ without any hook -- exports the true lists."""
+    from torch.utils import dlpack
+    from street_crafter_amd import rendering
+    g = _load(golden_dir, "pipeline_small.npz")
+    a = (_t(g["means2d"])[None], _t(g["radii"], torch.int32)[None], _t(g["depths"])[None], 16, 8, 6)
+    prev = (rendering.set_deferred_isect(placeholders), rendering.set_lazy_isect_ids(placeholders))
+    try:
+        rendering.reset_state()
+        for rep in range(3):             # (the deferral starts with the second call of a frame shape)
+            tpg, ids, fids = ops.isect_tiles(*a, n_cameras=1)
+            if placeholders:
+                got_f = torch.from_dlpack(fids)                  # the protocol: settles first
+                got_i = torch.from_dlpack(ids)
+                if rep:                      # (the first call of a frame shape has no prediction: plain tensors)
+                    assert type(fids) is not torch.Tensor and fids.is_materialized
+                    again = dlpack.from_dlpack(dlpack.to_dlpack(fids.materialize()))
+                    assert torch.equal(again, got_f)
+            else:
+                assert type(fids) is torch.Tensor and type(ids) is torch.Tensor
+                got_f = dlpack.from_dlpack(dlpack.to_dlpack(fids))          # legacy capsule, no torch call in between
+                got_i = dlpack.from_dlpack(dlpack.to_dlpack(ids))
+            np.testing.assert_array_equal(_np(got_f), g["flatten_ids"])
+            np.testing.assert_array_equal(_np(got_i), g["isect_ids"])
+            np.testing.assert_array_equal(_np(ops.isect_offset_encode(ids, 1, 8, 6)), g["isect_offsets"])
+    finally:
+        rendering.set_deferred_isect(prev[0])
+        rendering.set_lazy_isect_ids(prev[1])
+        rendering.reset_state()
+
+
 @pytest.mark.parametrize("which", ["golden", "iid", "big_splats", "two_cameras", "odd_frame"])
 def test_isect_pull_route_is_bit_exact(ops, golden_dir, which):
     """sc_set_option("isect_pull", 1): every super-tile bucket's sort workgroup gathers its records itself from a (size class,
@@ -1968,7 +2004,7 @@ def test_isect_pull_route_is_bit_exact(ops, golden_dir, which):
             for rep in range(2):           # (second call: predicted sizes, deferred settle)
                 tpg, ids, fids = ops.isect_tiles(m2, radii, d, 16, tw, th, n_cameras=C)
                 if which == "big_splats" and rep == 0:      # the case is there for the oversized-bucket path
-                    assert list(rendering._BIN_LAST_META.values())[-1][2] > _lib.load().sc_isect_bin_bucket_capacity()
+                    assert list(rendering._STATE.last_meta.values())[-1][2] > _lib.load().sc_isect_bin_bucket_capacity()
                 off = ops.isect_offset_encode(ids, C, tw, th)
                 np.testing.assert_array_equal(_np(tpg), e_tpg)
                 np.testing.assert_array_equal(_np(off), e_off)

@@ -40,7 +40,7 @@ for yaw in (0.0, 0.2):
             same = a.shape == b.shape and bool((a == b).all())
             bad += 0 if same else 1
             print(f"{which} yaw {yaw}: {nm} {'equal' if same else 'DIFFERENT'} ({a.numel()} elements)")
-        key = [k for k in rendering._BIN_LAST_META][-1]
-        print("  (n_isects, n_records, largest bucket) =", rendering._BIN_LAST_META[key])
+        key = [k for k in rendering._STATE.last_meta][-1]
+        print("  (n_isects, n_records, largest bucket) =", rendering._STATE.last_meta[key])
 print("OK" if bad == 0 else f"FAILED: {bad} tensors differ")
 sys.exit(1 if bad else 0)

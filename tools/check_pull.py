@@ -53,7 +53,7 @@ for name in which:
                 out[route] = (tpg.clone(), torch.as_tensor(ids).clone(), torch.as_tensor(fids).clone(), off.clone())
                 times[route] = sorted(ts[1:])[len(ts[1:]) // 2] if len(ts) > 1 else ts[0]
                 if route != "radix":
-                    meta = list(rendering._BIN_LAST_META.values())[-1]
+                    meta = list(rendering._STATE.last_meta.values())[-1]
                 _lib.set_option("isect_pull", prev_pull)
                 rendering.set_isect_mode(prev_mode)
         names = ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets")

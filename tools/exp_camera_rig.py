@@ -47,21 +47,21 @@ def run(sc, cams):
 def frames_per_s(sc, cams, hist_len):
     """whole frames (one stream), and how often the speculative sort launch had been sized too small"""
     import time
-    rendering._BIN_HISTORY.clear()
-    rendering._BIN_HISTORY_LEN = hist_len
+    rendering._STATE.history.clear()
+    rendering._STATE.history_len = hist_len
     with torch.no_grad():
         for c in cams[:6]:
             render_gaussians(sc, c)
         torch.cuda.synchronize()
-        s0 = dict(rendering._BIN_STATS)
+        s0 = dict(rendering._STATE.stats)
         t0 = time.perf_counter()
         for c in cams[6:]:
             render_gaussians(sc, c)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    rendering._BIN_HISTORY_LEN = 8
-    rendering._BIN_HISTORY.clear()
-    return (len(cams) - 6) / dt, rendering._BIN_STATS["exact_relaunch"] - s0["exact_relaunch"]
+    rendering._STATE.history_len = 8
+    rendering._STATE.history.clear()
+    return (len(cams) - 6) / dt, rendering._STATE.stats["exact_relaunch"] - s0["exact_relaunch"]
 
 
 for name, sc in scenes.items():

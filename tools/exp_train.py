@@ -22,7 +22,7 @@ STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 dev = "cuda"
 if os.environ.get("SC_NO_CAP_CLAMP"):      # A/B: predicted bucket capacity with its head-room, whatever it crosses (before the clamp)
     from street_crafter_amd import rendering as _r
-    _r._BUCKET_CAP["v"] = 1 << 40
+    _r._STATE.bucket_cap["v"] = 1 << 40
 if os.environ.get("SC_NATIVE_AUTOGRAD") == "0":      # A/B: the Python torch.autograd.Functions instead of the C++ ones
     from street_crafter_amd import rendering as _r
     _r.set_native_autograd(False)

@@ -72,7 +72,7 @@ for it in range(ROUNDS):
             continue
         ok_isect = all(torch.equal(a, b) for a, b in zip(outs["bin"], outs["radix"]))
         if not ok_isect:
-            print("    bucketed route meta (n_isects, n_records, largest super-tile):", list(rendering._BIN_LAST_META.values())[-1:])
+            print("    bucketed route meta (n_isects, n_records, largest super-tile):", list(rendering._STATE.last_meta.values())[-1:])
             offb = outs["radix"][3].reshape(-1).long()
             dd = (outs["bin"][2] != outs["radix"][2]).nonzero().reshape(-1)
             tiles_bad = torch.unique(torch.searchsorted(offb, dd, right=True) - 1)
