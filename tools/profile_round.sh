@@ -4,7 +4,7 @@
 # flight, the default) and of the same frames one at a time, of the street scenes and of the train step, and
 # the PMC passes.  Copy the *.md / *.json you want judged into profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 python3 bench.py --steps 50 --warmup 5 > $O/${TAG}_bench_1gpu_S1M.jsonl 2> $O/${TAG}_bench.err; echo "bench rc=$?"
