@@ -42,7 +42,7 @@ OPERATOR_KERNEL = {
     "isect_tiles": "bin_count + center_scatter + bin_scatter_flat + super_sort (4 kernels)",
     "isect_offset_encode": "(none: cached bucket scan)",
     "spherical_harmonics": "sh_fwd_kernel",
-    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false, false, false>",
+    "rasterize_to_pixels": "raster_fwd_wave_kernel<4, false, false, false, true>",
 }
 
 
@@ -448,6 +448,10 @@ def run_rank(args):
             _lib.set_option("raster_fwd", args.raster_variant)
         if args.interleaved_output:
             rendering.set_planar_output(False)
+        # (the forward's kernel symbol carries the output layout: template arguments CDIM, TRACK, PACKED, ED, PLANAR)
+        OPERATOR_KERNEL["rasterize_to_pixels"] = ("raster_fwd_wave_kernel<4, false, false, false, true>"
+                                                  if rendering._SWITCH.planar_out else
+                                                  "raster_fwd_wave_kernel<4, false, false, false, false>")
         if args.scene_ply:
             # a scene in the reference's point_cloud.ply layout (street_crafter_amd/scene_io.py); actors, if
             # any, are placed with identity poses.  Not the headline workload: the metric string stays S-1M's.
