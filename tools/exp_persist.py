@@ -1,4 +1,5 @@
-"""A/B of the PERSISTENT forward rasterizer (sc_set_option "raster_persist" = one-wave workgroups per CU that pop the dispatch
+"""(Needs tools/patches/r04_raster_persist.diff applied: the shipped library has no "raster_persist" option.)
+A/B of the PERSISTENT forward rasterizer (sc_set_option "raster_persist" = one-wave workgroups per CU that pop the dispatch
 list) through the reference caller sequence -> uint8 frame: frames/s with 1 and 3 frames in flight; frames compared bit for bit.
     python tools/exp_persist.py [values,comma] [n_gauss|street] [frames] [rounds]"""
 import os, sys, time
