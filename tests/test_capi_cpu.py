@@ -64,6 +64,23 @@ def test_argument_validation_without_gpu(lib):
                                 None, None, 0, None, None, None, None, None, None) == -1        # tiles too few
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 10, 65, None, 0, None) == -1
     assert lib.sc_radix_sort_pairs_u64_i32(None, None, None, None, 1, 40, None, 0, None) == 0   # n<=1 no-op
+    # round 4: planar rasterizer output, strided frame export, stream factory -- rejected before any launch / HIP call
+    assert lib.sc_rasterize_fwd_planar(None, None, None, None, None, None, 1, 4, 33, 64, 64, 16, 4, 4,
+                                       None, None, 0, None, None, None, None, None) == -1               # D > 32
+    assert lib.sc_rasterize_fwd_planar(None, None, None, None, None, None, 0, 4, 4, 64, 64, 16, 4, 4,
+                                       None, None, 0, None, None, None, None, None) == 0                # C == 0: nothing to do
+    assert lib.sc_frame_composite_u8_strided(None, 0, 1, None, None, 1, 1, 10, 0, None, None) == -1     # pixel stride < 1
+    assert lib.sc_frame_composite_u8_strided(None, 1, 1, None, None, 1, 1, 0, 0, None, None) == 0       # no pixels
+    assert lib.sc_frame_composite_u8_strided(None, 1, 1, None, None, 1, 1, 10, 2, None, None) == -1     # rounding mode
+    assert lib.sc_stream_create(0, None, 0, None) == -1                                                 # no place for the handle
+    assert lib.sc_stream_create(0, None, 4, ctypes.byref(ctypes.c_void_p())) == -1                      # mask words without a mask
+    zero_mask = (ctypes.c_uint32 * 8)()
+    assert lib.sc_stream_create(0, ctypes.cast(zero_mask, ctypes.c_void_p), 8, ctypes.byref(ctypes.c_void_p())) == -1   # empty mask
+    assert lib.sc_stream_destroy(None) == -1 and lib.sc_stream_priority_range(None, None) == -1
+    for key, bad in ((b"proj_clamp", 2), (b"radius_floor", 2), (b"isect_pull", 2)):
+        assert lib.sc_set_option(key, bad) == -1
+        prev = lib.sc_set_option(key, 1)
+        assert prev in (0, 1) and lib.sc_set_option(key, prev) == 1
     # fused forward entries
     assert lib.sc_camera_centers(None, -1, None, None) == -1
     assert lib.sc_camera_centers(None, 0, None, None) == 0
