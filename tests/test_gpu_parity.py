@@ -1898,6 +1898,42 @@ def test_planar_output_is_the_same_tensor_by_value(ops, w, h, D, use_bg, use_mas
     assert c2.is_contiguous() and torch.equal(c2.detach(), c0)
 
 
+def test_planar_output_with_two_cameras_and_the_two_pass_frame(ops):
+    """Planes per camera ([C][D][H][W]) behind the [C,H,W,D] indexing, and the two-pass novel-view frame (foreground planar or not,
+    sky planar or not: dist.to_uint8_frame reads either layout off the strides) -- identical values in every combination."""
+    from street_crafter_amd import rendering
+    from street_crafter_amd.dist import to_uint8_frame
+    w, h, C = 200, 120, 2
+    sc = make_scene(12_000, seed=41, z_range=(1.0, 30.0), scale_range=(0.02, 0.5))
+    cams = [make_camera(w, h, 220.0, 220.0, yaw=0.15 * c) for c in range(C)]
+    with torch.no_grad():
+        radii, m2, d, con, comp = ops.fully_fused_projection(
+            sc.means.to(DEV), None, sc.quats.to(DEV), sc.scales.to(DEV), torch.stack([c.viewmat for c in cams]).to(DEV),
+            torch.stack([c.K for c in cams]).to(DEV), w, h, near_plane=0.001, far_plane=1000.0, calc_compensations=True)
+        tw, th = (w + 15) // 16, (h + 15) // 16
+        _, ids, fids = ops.isect_tiles(m2, radii, d, 16, tw, th, n_cameras=C)
+        off = ops.isect_offset_encode(ids, C, tw, th)
+        colors = torch.rand(C, sc.n, 4, generator=torch.Generator().manual_seed(4)).to(DEV)
+        opac = (sc.opacities[None, :, 0].to(DEV) * comp).contiguous()
+        outs = {}
+        for planar in (False, True):
+            prev = rendering.set_planar_output(planar)
+            try:
+                outs[planar] = ops.rasterize_to_pixels(m2, con, colors, opac, w, h, 16, off, fids)
+            finally:
+                rendering.set_planar_output(prev)
+        (c0, a0), (c1, a1) = outs[False], outs[True]
+        assert c1.stride() == (4 * h * w, w, 1, h * w) and torch.equal(c0, c1) and torch.equal(a0, a1)
+        assert float(a0[1].sum()) > 0 and not torch.equal(c0[0], c0[1])
+        # camera 0 as the foreground pass, camera 1 standing in for the sky pass: all four layout combinations
+        ref = None
+        for fg, sky in ((c0, c0), (c1, c0), (c0, c1), (c1, c1)):
+            f = to_uint8_frame(fg[0, ..., :3].permute(2, 0, 1), acc=a0[0, ..., 0], sky_rgb_chw=sky[1, ..., :3].permute(2, 0, 1))
+            ref = f if ref is None else ref
+            assert torch.equal(f, ref)
+        assert int(ref.max()) > 0
+
+
 def test_rasterizer_on_a_cu_masked_or_prioritised_side_stream_renders_the_same_frames(ops):
     """rendering.set_raster_side_stream + dist.make_stream (sc_stream_create): the inference rasterizer handed to a stream
     confined to 64 of the CUs, or of the lowest priority, fenced by events -- frames identical to the plain loop, with two
