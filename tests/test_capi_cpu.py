@@ -447,6 +447,13 @@ def test_lazy_tensor_with_a_deferred_shape():
     for fn in (copy.deepcopy, lambda t: pickle.loads(pickle.dumps(t)), lambda t: t.clone()):
         out = fn(make())
         assert type(out) is torch.Tensor and out.tolist() == [0, 5, 10, 15]
+    # the DLPack PROTOCOL asks the object (LazyTensor.__dlpack__ settles first); the legacy capsule call unwraps the tensor in
+    # C++ without any hook and exports the placeholder: the documented hazard (SC_DEFER_ISECT=0 SC_LAZY_IDS=0)
+    from torch.utils import dlpack
+    log.clear()
+    assert torch.from_dlpack(make()).tolist() == [0, 5, 10, 15] and log == ["resolve", "fill"]
+    assert dlpack.from_dlpack(dlpack.to_dlpack(make())).shape == (0,)
+    assert dlpack.from_dlpack(dlpack.to_dlpack(make().materialize())).tolist() == [0, 5, 10, 15]
     t = make(fill=False)                  # no contents to produce (flatten_ids: the sort has written them)
     assert type(t.plain()) is torch.Tensor and t.plain().shape == (4,) and t.plain().data_ptr() == cap.data_ptr()
 

@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-python3 bench.py --steps 50 --warmup 5 > $O/${TAG}_bench_1gpu_S1M.jsonl 2> $O/${TAG}_bench.err; echo "bench rc=$?"
+python3 bench.py --steps 50 --warmup 5 --cpu-python-frames 3 > $O/${TAG}_bench_1gpu_S1M.jsonl 2> $O/${TAG}_bench.err; echo "bench rc=$?"
 prof() {  # name frames cmd...
   local name=$1 frames=$2; shift 2
   rm -rf $O/prof_tmp
