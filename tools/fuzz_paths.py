@@ -18,6 +18,8 @@ from street_crafter_amd.scenes import make_camera, make_scene, make_street_scene
 if os.environ.get("FUZZ_LIB"):       # FUZZ_LIB=tag: check an experiment build (SC_DIAG_TAG=tag ... build --diag) instead of the shipped library
     _lib.use_diagnostic_build("" if os.environ["FUZZ_LIB"] == "diag" else os.environ["FUZZ_LIB"])
     _lib.set_fast_binding(False)     # (the compiled binding layer is linked to the shipped library)
+if os.environ.get("FUZZ_PULL"):      # FUZZ_PULL=1: the bucketed route under test is the PULL route (sc_set_option "isect_pull")
+    _lib.set_option("isect_pull", 1)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ROUNDS = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 bad = 0
