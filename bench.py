@@ -406,6 +406,10 @@ def run_rank(args):
             sys.exit(2)
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+        if placement is not None:          # which GPU did LOCAL_RANK really select?  (dist.verify_rank_binding)
+            from street_crafter_amd.dist import verify_rank_binding
+            placement = verify_rank_binding(placement, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                            getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
         if world > 1:
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
@@ -568,8 +572,7 @@ def run_rank(args):
     placements = None
     if world > 1 and not selftest:
         placements = [None] * world
-        dist.all_gather_object(placements, dict(placement or {}, rank=rank, device=str(dev),
-                                                pci_of_device=getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)))
+        dist.all_gather_object(placements, dict(placement or {}, rank=rank, device=str(dev)))
     gathered_ok = None
     if rank == 0 and world > 1 and not selftest:
         # every rank's first timed frame, as it arrived through the gather, against a local re-render of that frame

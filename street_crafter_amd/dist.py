@@ -472,6 +472,36 @@ def bind_rank(local_rank: int, n_local: int, sysfs: str = "/sys", num_threads: i
     return info
 
 
+def verify_rank_binding(info: Dict, local_rank: int, n_local: int, pci_bus: Optional[int], sysfs: str = "/sys") -> Dict:
+    """After the first GPU call: bind_rank chose this rank's CPUs by the GPU's position in the KFD topology, which is HIP's
+    default device order; `pci_bus` (torch.cuda.get_device_properties(dev).pci_bus_id) says which GPU the rank really got.  If
+    that is another entry of the topology (a reordered HIP_VISIBLE_DEVICES), every thread of the process is moved to that
+    GPU's share of CPUs instead.  Returns the updated record."""
+    info = dict(info or {})
+    info["pci_bus_of_device"] = pci_bus
+    if not info.get("bound") or pci_bus is None:
+        return info
+    topo = gpu_host_topology(sysfs)
+    mine = [g for g in topo if int(g["pci"].split(":")[1], 16) == int(pci_bus)]
+    if not mine or mine[0]["index"] == local_rank:
+        info["binding_verified"] = bool(mine)
+        return info
+    try:
+        # (no intersection with the current affinity: the first binding has already narrowed this thread to the wrong share)
+        cpus = cpus_for_local_rank(topo, mine[0]["index"], max(n_local, mine[0]["index"] + 1), None)
+        if cpus:
+            for tid in os.listdir("/proc/self/task"):
+                try:
+                    os.sched_setaffinity(int(tid), cpus)
+                except OSError:
+                    pass
+            info.update(cpus=f"{cpus[0]}-{cpus[-1]} ({len(cpus)})", numa_node=mine[0]["numa_node"], pci=mine[0]["pci"],
+                        rebound_after_init=True)
+    except (AttributeError, OSError) as e:
+        info["rebind_error"] = str(e)
+    return info
+
+
 # ---- single-node launcher -----------------------------------------------------------------------
 def free_port() -> int:
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:

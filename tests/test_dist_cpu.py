@@ -273,6 +273,16 @@ def test_rank_placement_maps_every_rank_to_its_gpus_numa_cpus(tmp_path):
                                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip().splitlines()[-1])
     if len(allowed) >= 2:
         assert info["bound"] and now == allowed[len(allowed) // 2:][:len(allowed) // 2] and info["numa_node"] == 0
+    # verify_rank_binding: the device the rank really got sits at ANOTHER position of the topology -> every thread moves there
+    code2 = ("import json, os, sys; sys.path.insert(0, %r); from street_crafter_amd import dist as D; "
+             "i = D.bind_rank(0, 2, sysfs=%r); j = D.verify_rank_binding(i, 0, 2, 0x21, sysfs=%r); "
+             "k = D.verify_rank_binding(i, 0, 2, 0x20, sysfs=%r); "
+             "print(json.dumps([j, sorted(os.sched_getaffinity(0)), k]))" % (os.getcwd(), root3, root3, root3))
+    j, now2, k = json.loads(subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True,
+                                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip().splitlines()[-1])
+    if len(allowed) >= 2:
+        assert j.get("rebound_after_init") and now2 == allowed[len(allowed) // 2:][:len(allowed) // 2] and j["pci"] == "0000:21:00.0"
+        assert k.get("binding_verified") and not k.get("rebound_after_init")
     off = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
                          env=dict(os.environ, SC_BIND_CPUS="0"),
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))).stdout.strip().splitlines()[-1]
