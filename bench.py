@@ -335,6 +335,15 @@ def main():
     run_rank(args)
 
 
+def _rccl_version(torch):
+    """RCCL's version as torch reports it (never worth failing a multi-GPU run over)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(map(str, v)) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:      # noqa: BLE001
+        return f"unavailable ({type(e).__name__})"
+
+
 def init_world1(dev):
     """init_process_group("nccl", world_size=1): the same call a rank of an N > 1 job makes, on the one GPU here."""
     import torch.distributed as dist
@@ -572,7 +581,10 @@ def run_rank(args):
     placements = None
     if world > 1 and not selftest:
         placements = [None] * world
-        dist.all_gather_object(placements, dict(placement or {}, rank=rank, device=str(dev)))
+        try:
+            dist.all_gather_object(placements, dict(placement or {}, rank=rank, device=str(dev)))
+        except Exception as e:      # noqa: BLE001  (diagnostics only: the measured value stands without them)
+            placements = [f"not gathered ({type(e).__name__}: {e})"]
     gathered_ok = None
     if rank == 0 and world > 1 and not selftest:
         # every rank's first timed frame, as it arrived through the gather, against a local re-render of that frame
@@ -592,7 +604,7 @@ def run_rank(args):
             "per_rank_frames_per_s": per_rank_fps, "gathered_frames_match_local_render": gathered_ok,
             "ranks": None if placements is None else {
                 "placement": placements,
-                "rccl_version": ".".join(map(str, torch.cuda.nccl.version())) if args.backend == "nccl" else None,
+                "rccl_version": _rccl_version(torch) if args.backend == "nccl" else None,
                 "devices_visible_per_rank": "all (torch.cuda.set_device(LOCAL_RANK)): RCCL's xGMI transport maps peer buffers "
                                             "through hipIpc / peer access, which needs the peers enumerated in the process",
                 "what": "dist.bind_rank before the first GPU call: host threads of every rank on the CPUs local to its GPU's "
