@@ -397,8 +397,11 @@ def run_rank(args):
         os.environ.setdefault("NCCL_DEBUG", "VERSION")      # (RCCL states its version once, on stderr; the line carries it too)
         if not selftest and not args.oversubscribe:
             # before the first GPU call: this rank's host threads onto the CPUs of its GPU's NUMA node (dist.bind_rank)
-            from street_crafter_amd.dist import bind_rank
-            placement = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            try:
+                from street_crafter_amd.dist import bind_rank
+                placement = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            except Exception as e:      # noqa: BLE001  (placement is an optimisation: never a reason to lose the run)
+                placement = {"bound": False, "why": f"{type(e).__name__}: {e}"}
     if selftest:
         dev = torch.device("cpu")
         if world > 1:
@@ -416,9 +419,12 @@ def run_rank(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         if placement is not None:          # which GPU did LOCAL_RANK really select?  (dist.verify_rank_binding)
-            from street_crafter_amd.dist import verify_rank_binding
-            placement = verify_rank_binding(placement, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
-                                            getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
+            try:
+                from street_crafter_amd.dist import verify_rank_binding
+                placement = verify_rank_binding(placement, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                                getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
+            except Exception as e:      # noqa: BLE001
+                placement = dict(placement, verify_error=f"{type(e).__name__}: {e}")
         if world > 1:
             if args.backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
